@@ -1,0 +1,160 @@
+/*
+ * tsu_hip.h -- C ABI of libtsu_hip.so: the MI355X (gfx950) stochastic spin-update hot path.
+ *
+ * The reference (Arsham-001/tsu-emulator) is pure Python/NumPy and has NO FFI: its boundary for this
+ * path is the Python method surface of tsu/gibbs.py, tsu/models/ising.py and tsu/core.py.  This header
+ * is the boundary a host-language binding would bind instead; every entry point names the reference
+ * interface it replaces (file:line under /root/reference).  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++ / torch types.
+ *   - every function returns int: TSU_OK or a negative TSU_E_*; tsu_last_error() gives the text.
+ *     No exceptions or longjmp cross the ABI.
+ *   - the caller owns all host buffers (never retained past the call); the library owns device
+ *     memory behind opaque handles with explicit create/destroy.
+ *   - handles are not thread-safe; one tsu_ctx per process per device.
+ *   - all work is enqueued on the ctx stream (tsu_set_stream; default: the null stream).  Calls that
+ *     copy results to host memory synchronise that stream before returning; pure device calls
+ *     (sweep, step, randomize) are asynchronous.
+ *   - randomness is counter-based Philox4x32-10 keyed by (seed, position, sweep/step counter): results
+ *     do not depend on launch geometry, tile size, number of sweeps per call, or slab decomposition.
+ */
+#ifndef TSU_HIP_H
+#define TSU_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSU_OK 0
+#define TSU_E_INVALID (-1)     /* bad argument (Python side raises ValueError / ConfigurationError) */
+#define TSU_E_NOMEM (-2)       /* host or device allocation failed */
+#define TSU_E_HIP (-3)         /* a HIP runtime call failed */
+#define TSU_E_RCCL (-4)        /* reserved: collective failure */
+#define TSU_E_UNSUPPORTED (-5) /* valid request this build has no kernel for */
+
+#define TSU_MODE_PHYSICAL 0 /* corrected spin->bit bias: P(+1) = sigmoid(2 (J nsum + h) / T) */
+#define TSU_MODE_COMPAT 1   /* bias exactly as tsu/models/ising.py:148 (bug-for-bug) */
+
+#define TSU_DTYPE_F64 0
+#define TSU_DTYPE_F32 1
+
+#define TSU_KERNEL_AUTO 0    /* pick the fastest kernel that supports the lattice */
+#define TSU_KERNEL_GENERIC 1 /* one colour per launch, global memory, any shape / boundary */
+#define TSU_KERNEL_TILED 2   /* LDS-staged halo tiles, several sweeps per launch */
+
+typedef struct tsu_ctx tsu_ctx;
+typedef struct tsu_ising2d tsu_ising2d;
+typedef struct tsu_dense tsu_dense;
+typedef struct tsu_langevin tsu_langevin;
+
+/* ------------------------------------------------------------------ context */
+int tsu_version(void);
+/* device < 0: use the current HIP device.  Fails with TSU_E_HIP when no GPU is present. */
+int tsu_init(int device, tsu_ctx** ctx);
+int tsu_shutdown(tsu_ctx* ctx);
+/* last error text of this ctx (ctx == NULL: of the last failed tsu_init on this thread) */
+const char* tsu_last_error(const tsu_ctx* ctx);
+/* run on the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = null stream */
+int tsu_set_stream(tsu_ctx* ctx, void* hip_stream);
+int tsu_synchronize(tsu_ctx* ctx);
+int tsu_device_info(tsu_ctx* ctx, char* name, int name_len, int* compute_units, uint64_t* hbm_bytes);
+/* hipEvent pair on the ctx stream: begin records, end records + synchronises and returns elapsed ms */
+int tsu_timer_begin(tsu_ctx* ctx);
+int tsu_timer_end(tsu_ctx* ctx, float* elapsed_ms);
+/* n Philox4x32-10 blocks evaluated ON THE DEVICE (known-answer tests): ctrs n*4, key 2, out n*4 */
+int tsu_philox4x32_10(tsu_ctx* ctx, int n, const uint32_t* ctrs, const uint32_t* key, uint32_t* out);
+
+/* ------------------------------------------------------------------ 2-D lattice (K1, K4)
+ * Replaces, for IsingGrid-shaped problems, the dense path
+ *   IsingGrid.__init__           tsu/models/ising.py:320-361   (lattice instead of an N x N matrix)
+ *   IsingModel.sample            tsu/models/ising.py:150-181
+ *   GibbsSampler.gibbs_sweep     tsu/gibbs.py:128-162          (one call of tsu_ising2d_sweep)
+ *   GibbsSampler.sample_conditional / _compute_local_field / _sigmoid   tsu/gibbs.py:61-126
+ *   IsingModel.energy / magnetization   tsu/models/ising.py:99-117,183-193  (tsu_ising2d_observables)
+ * Visiting order is red-black checkerboard (colour (row+col)&1 == 0 first), not raster order: the
+ * same heat-bath kernel and stationary distribution, a different trajectory.
+ */
+
+/* Host helper: acceptance thresholds table[deg*5 + up] in [0, 2^32] for coupling J, uniform field h,
+ * temperature T (gibbs.py:61-77,125 with ising.py:138,148 folded in).  Pure host arithmetic. */
+int tsu_ising2d_thresholds(double J, double h, double T, int mode, uint64_t table[25]);
+
+/* A whole rows x cols lattice on one GPU.  periodic needs even rows, cols >= 4 (2-colourability). */
+int tsu_ising2d_create(tsu_ctx* ctx, int rows, int cols, int periodic, tsu_ising2d** out);
+/* A row slab [row0, row0+rows) of a total_rows x cols lattice with `ghost` ghost rows on each side
+ * that the host refreshes from the neighbouring ranks (see tsu_ising2d_row_ptr).  ghost must be even
+ * and >= 2; at most ghost/2 sweeps may run between two refreshes. */
+int tsu_ising2d_create_slab(tsu_ctx* ctx, int64_t total_rows, int cols, int periodic, int64_t row0, int rows,
+                            int ghost, tsu_ising2d** out);
+int tsu_ising2d_destroy(tsu_ising2d* lat);
+
+/* +-1 int8 spins, row-major, `cols` bytes per row, local rows [row_first, row_first + n_rows) */
+int tsu_ising2d_set_spins(tsu_ising2d* lat, const int8_t* host, int row_first, int n_rows);
+int tsu_ising2d_get_spins(tsu_ising2d* lat, int8_t* host, int row_first, int n_rows);
+/* i.i.d. +-1 from Philox (replaces np.random.randint(0,2,N), gibbs.py:201, for lattices too big to stage) */
+int tsu_ising2d_randomize(tsu_ising2d* lat, uint64_t seed, uint32_t replica);
+int tsu_ising2d_fill(tsu_ising2d* lat, int8_t value);
+
+/* thresholds used by the following sweeps: explicit table, or J/h/T/mode through the helper above.
+ * T is a per-call quantity because callers mutate config.temperature in place (gibbs.py:382). */
+int tsu_ising2d_set_thresholds(tsu_ising2d* lat, const uint64_t table[25]);
+int tsu_ising2d_set_model(tsu_ising2d* lat, double J, double h, double T, int mode);
+int tsu_ising2d_set_kernel(tsu_ising2d* lat, int kernel, int sweeps_per_launch);
+
+/* n_sweeps full checkerboard sweeps, sweep counters sweep0 .. sweep0+n_sweeps-1 (asynchronous).
+ * For a slab: ghost rows must be fresh on entry and n_sweeps <= ghost/2. */
+int tsu_ising2d_sweep(tsu_ising2d* lat, int n_sweeps, uint64_t seed, uint32_t sweep0, uint32_t replica);
+
+/* sum_s = sum of spins, sum_bonds = sum over nearest-neighbour bonds of s_i*s_j (owned rows; the bond to
+ * the row below the slab is included when that row exists).  M = sum_s/N, E = -J*sum_bonds - h*sum_s. */
+int tsu_ising2d_observables(tsu_ising2d* lat, int64_t* sum_s, int64_t* sum_bonds);
+
+/* device address of local row r in [-ghost, rows+ghost) and the row pitch in bytes, for halo exchange
+ * by the host (RCCL send/recv through torch.distributed on the same stream) */
+int tsu_ising2d_row_ptr(tsu_ising2d* lat, int local_row, void** device_ptr, size_t* pitch_bytes);
+/* milliseconds of the most recent tsu_ising2d_sweep measured with HIP events (synchronises) */
+int tsu_ising2d_last_sweep_ms(tsu_ising2d* lat, float* ms);
+
+/* ------------------------------------------------------------------ dense coupling matrix (K2)
+ * Replaces GibbsSampler.gibbs_sweep / sample_boltzmann / compute_energy on a dense J
+ *   tsu/gibbs.py:79-100 (_compute_local_field incl. the diagonal term), :102-126, :128-162, :215-236.
+ * Visiting order is the reference's: range(n), or the caller's permutation (np.random.permutation).
+ * State is {0,1} int8 on the device; the Python layer converts to the caller's dtype.
+ */
+int tsu_dense_create(tsu_ctx* ctx, int n, const void* J_host, int dtype, const double* bias_host /*nullable*/,
+                     tsu_dense** out);
+int tsu_dense_destroy(tsu_dense* d);
+int tsu_dense_set_state(tsu_dense* d, const int8_t* bits_host);
+int tsu_dense_get_state(tsu_dense* d, int8_t* bits_host);
+/* order: NULL or n_sweeps*n site indices.  replay_uniforms: NULL (Philox doubles keyed by site and
+ * sweep0+s) or n_sweeps*n doubles consumed in visiting order (replays np.random.rand, gibbs.py:126). */
+int tsu_dense_sweep(tsu_dense* d, double T, int n_sweeps, const int64_t* order, uint64_t seed, uint32_t sweep0,
+                    uint32_t replica, const double* replay_uniforms);
+int tsu_dense_energy(tsu_dense* d, double* energy); /* -1/2 s^T J s - b^T s of the resident state */
+
+/* ------------------------------------------------------------------ Langevin (K3)
+ * Replaces ThermalSamplingUnit._langevin_step (tsu/core.py:64-80) fused with the analytic gradient of a
+ * separable quadratic energy E = 1/2 sum_i k_i (x_i - mu_i)^2 (replacing _numerical_gradient, :82-98),
+ * for n_chains independent chains (the restarts of sample_from_energy, :140-159), float32 on the device.
+ */
+int tsu_langevin_create(tsu_ctx* ctx, int n_chains, int dim, tsu_langevin** out);
+int tsu_langevin_destroy(tsu_langevin* l);
+int tsu_langevin_set_state(tsu_langevin* l, const float* x_host);               /* n_chains*dim */
+int tsu_langevin_get_state(tsu_langevin* l, float* x_host);
+int tsu_langevin_set_energy(tsu_langevin* l, const float* k_host, const float* mu_host); /* dim each */
+/* x <- x_init + amp * N(0,1) per chain (core.py:142-143); chain c uses Philox chain id chain0+c */
+int tsu_langevin_restart(tsu_langevin* l, const float* x_init_host /*dim*/, float amp, uint64_t seed,
+                         uint32_t chain0);
+/* n_steps fused steps, step counters step0.. ; traj_host (nullable): n_steps*n_chains*dim floats */
+int tsu_langevin_step(tsu_langevin* l, int n_steps, float dt, float gamma, float T, uint64_t seed, uint32_t step0,
+                      uint32_t chain0, float* traj_host);
+int tsu_langevin_set_kernel(tsu_langevin* l, int steps_per_launch); /* 0 = auto (fuse in registers) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSU_HIP_H */

@@ -162,13 +162,14 @@ void ora_ising2d_randomize(int8_t *spins, int rows, int cols, int64_t row0, uint
     }
 }
 
-/* 32-bit uniform of site (R = global row, c) in half-sweep hs: hi16 from TAG_ISING_HI, lo16 from TAG_ISING_LO */
+/* 32-bit uniform of site (R = global row, c) in half-sweep hs: hi16 from TAG_ISING_HI (top bit flipped, a
+ * bijection that lets the device compare raw Philox halves as SIGNED 16-bit values), lo16 from TAG_ISING_LO */
 static inline uint32_t site_uniform(uint32_t R, int c, uint32_t hs, uint64_t seed, uint32_t replica) {
     uint32_t j = (uint32_t)c >> 1, o = j >> 3, m = j & 7;
     uint32_t whi[4], wlo[4];
     philox(o, R, hs, TAG_ISING_HI | (replica << 8), seed, whi);
     philox(o, R, hs, TAG_ISING_LO | (replica << 8), seed, wlo);
-    uint32_t hi = (whi[m >> 1] >> (16 * (m & 1))) & 0xFFFFu;
+    uint32_t hi = ((whi[m >> 1] >> (16 * (m & 1))) & 0xFFFFu) ^ 0x8000u; /* top bit flipped: see DESIGN.md */
     uint32_t lo = (wlo[m >> 1] >> (16 * (m & 1))) & 0xFFFFu;
     return (hi << 16) | lo;
 }
@@ -206,7 +207,7 @@ void ora_ising2d_sweep(int8_t *spins, int rows, int cols, int periodic, const ui
                         philox(o, (uint32_t)r, hs, TAG_ISING_HI | (replica << 8), seed, whi);
                         cached_o = (int)o;
                     }
-                    uint64_t hi = (whi[m >> 1] >> (16 * (m & 1))) & 0xFFFFu;
+                    uint64_t hi = ((whi[m >> 1] >> (16 * (m & 1))) & 0xFFFFu) ^ 0x8000u;
                     uint64_t thi = thr >> 16; /* 0..65536 */
                     int accept;
                     if (hi < thi) accept = 1;      /* hi*65536 + lo < thi*65536 <= thr */

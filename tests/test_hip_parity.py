@@ -1,0 +1,232 @@
+"""Parity tests proper (-m gpu): the HIP path, called through the C-ABI (ctypes), against the oracle on the
+same seeded inputs.  Bit-exact for spins / bits / integer observables; float tolerance stated per test."""
+import numpy as np
+import pytest
+
+from oracle import oracle as ora
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from tsu import _hip
+    _hip.Context.default()  # raises HipUnavailableError (test error, not skip) when the GPU path is missing
+    return _hip
+
+
+# ----------------------------------------------------------------------------- K5 Philox on the device
+def test_philox_kat_on_device(hip):
+    ctx = hip.Context.default()
+    kats = [((0, 0, 0, 0), (0, 0), (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)),
+            ((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2, (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)),
+            ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0),
+             (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1))]
+    for ctr, key, want in kats:
+        got = ctx.philox4x32_10([ctr], key)[0]
+        assert tuple(int(v) for v in got) == want
+    rng = np.random.default_rng(0)
+    ctrs = rng.integers(0, 2 ** 32, size=(1000, 4), dtype=np.uint64).astype(np.uint32)
+    key = np.array([123456789, 987654321], dtype=np.uint32)
+    got = ctx.philox4x32_10(ctrs, key)
+    want = np.array([ora.philox4x32_10(c, key) for c in ctrs])
+    np.testing.assert_array_equal(got, want)
+
+
+# ----------------------------------------------------------------------------- K1 lattice sweep
+LATTICES = [(8, 8, True), (32, 32, True), (64, 64, True), (4, 4, True), (6, 20, True), (130, 36, True),
+            (257, 130, False), (33, 47, False), (1, 9, False), (9, 1, False), (1, 1, False), (2, 2, False),
+            (5, 16, False), (16, 17, False), (64, 1024, True), (12, 2050, True)]
+
+
+@pytest.mark.parametrize("kernel", ["generic", "auto"])
+@pytest.mark.parametrize("rows,cols,periodic", LATTICES)
+def test_ising2d_sweep_bit_exact(hip, rows, cols, periodic, kernel):
+    seed = 1000 + rows * 31 + cols
+    for (J, h, T, mode) in [(1.0, 0.0, 2.269185, hip.MODE_PHYSICAL), (-0.7, 0.3, 1.1, hip.MODE_COMPAT)]:
+        table = ora.ising2d_thresholds(J, h, T, mode)
+        lat = hip.Lattice(rows, cols, periodic)
+        lat.set_kernel(hip.KERNEL_GENERIC if kernel == "generic" else hip.KERNEL_AUTO)
+        lat.randomize(seed)
+        s0 = lat.get_spins()
+        np.testing.assert_array_equal(s0, ora.ising2d_randomize(rows, cols, seed))
+        lat.set_thresholds(table)
+        lat.sweep(1, seed, sweep0=0)
+        want = ora.ising2d_sweep(s0, periodic, table, 1, seed, sweep0=0)
+        np.testing.assert_array_equal(lat.get_spins(), want)
+        lat.sweep(7, seed, sweep0=1)
+        want = ora.ising2d_sweep(want, periodic, table, 7, seed, sweep0=1)
+        got = lat.get_spins()
+        np.testing.assert_array_equal(got, want)
+        assert lat.observables() == ora.ising2d_observables(want, periodic)
+        lat.close()
+
+
+def test_ising2d_set_model_matches_oracle_thresholds(hip):
+    for (J, h, T, mode) in [(1.0, 0.0, 2.269185, 0), (1.0, 0.0, 2.5, 1), (-0.7, 0.3, 1.1, 0), (0.4, -0.2, 0.05, 1),
+                            (1.0, 0.0, 0.01, 0)]:
+        np.testing.assert_array_equal(hip.ising2d_thresholds(J, h, T, mode), ora.ising2d_thresholds(J, h, T, mode))
+    lat = hip.Lattice(16, 16, True)
+    lat.randomize(3)
+    s0 = lat.get_spins()
+    lat.set_model(1.0, 0.1, 2.0, hip.MODE_PHYSICAL)
+    lat.sweep(3, 3)
+    np.testing.assert_array_equal(lat.get_spins(), ora.ising2d_sweep(s0, True, ora.ising2d_thresholds(1.0, 0.1, 2.0, 0), 3, 3))
+
+
+def test_ising2d_ties_exercise_lazy_low_bits(hip):
+    """Coarse thresholds make hi16 ties frequent; thresholds 0 / 2^32 / 1 / 2^32-1 hit the clamps."""
+    rows, cols = 64, 96
+    s0 = ora.ising2d_randomize(rows, cols, 5)
+    for table in (np.array([(k * 0x0A3D) << 16 | 0x8000 for k in range(25)], dtype=np.uint64),
+                  np.array([0, 1 << 32, 1, (1 << 32) - 1, 65536] * 5, dtype=np.uint64)):
+        for periodic in (True, False):
+            lat = hip.Lattice(rows, cols, periodic)
+            lat.set_spins(s0)
+            lat.set_thresholds(table)
+            lat.sweep(6, 99, sweep0=11)
+            np.testing.assert_array_equal(lat.get_spins(), ora.ising2d_sweep(s0, periodic, table, 6, 99, sweep0=11))
+
+
+def test_ising2d_replica_and_fill(hip):
+    lat = hip.Lattice(16, 32, True)
+    lat.fill(-1)
+    assert (lat.get_spins() == -1).all()
+    lat.set_model(1.0, 0.0, 3.0)
+    lat.sweep(2, 7, replica=3)
+    want = ora.ising2d_sweep(-np.ones((16, 32), np.int8), True, ora.ising2d_thresholds(1.0, 0.0, 3.0, 0), 2, 7, replica=3)
+    np.testing.assert_array_equal(lat.get_spins(), want)
+
+
+def test_ising2d_argument_errors(hip):
+    with pytest.raises(hip.UnsupportedError):
+        hip.Lattice(5, 8, True)  # odd periodic dimension has no 2-colouring
+    with pytest.raises(ValueError):
+        hip.Lattice(0, 8, False)
+    lat = hip.Lattice(8, 8, False)
+    with pytest.raises(ValueError):
+        lat.sweep(1, 0)  # no thresholds yet
+    with pytest.raises(ValueError, match="Temperature must be positive"):
+        lat.set_model(1.0, 0.0, -1.0)
+
+
+@pytest.mark.parametrize("periodic", [True, False])
+@pytest.mark.parametrize("nslab,ghost,k", [(2, 2, 1), (4, 4, 2), (3, 8, 4)])
+def test_ising2d_slab_decomposition_invariance(hip, periodic, nslab, ghost, k):
+    """P row slabs with host-mediated ghost refresh every k sweeps == the whole lattice (globally keyed RNG)."""
+    rows, cols, seed = 24 * nslab, 40, 77
+    table = ora.ising2d_thresholds(1.0, 0.05, 2.3, 0)
+    full = ora.ising2d_randomize(rows, cols, seed)
+    per = rows // nslab
+    slabs = [hip.Lattice(per, cols, periodic, total_rows=rows, row0=i * per, ghost=ghost) for i in range(nslab)]
+    for i, s in enumerate(slabs):
+        s.randomize(seed)
+        np.testing.assert_array_equal(s.get_spins(), full[i * per:(i + 1) * per])
+        s.set_thresholds(table)
+    want = full
+    for it in range(3):
+        # ghost refresh: rows adjacent to each slab, taken from the neighbours' owned rows
+        owned = [s.get_spins() for s in slabs]
+        for i, s in enumerate(slabs):
+            up, dn = (i - 1) % nslab, (i + 1) % nslab
+            if periodic or i > 0:
+                s.set_spins(owned[up][-ghost:], row_first=-ghost)
+            if periodic or i < nslab - 1:
+                s.set_spins(owned[dn][:ghost], row_first=per)
+        for s in slabs:
+            s.sweep(k, seed, sweep0=it * k)
+        want = ora.ising2d_sweep(want, periodic, table, k, seed, sweep0=it * k)
+        got = np.concatenate([s.get_spins() for s in slabs])
+        np.testing.assert_array_equal(got, want)
+    # observables: per-slab sums add up to the whole-lattice values (ghost rows fresh)
+    owned = [s.get_spins() for s in slabs]
+    for i, s in enumerate(slabs):
+        if periodic or i < nslab - 1:
+            s.set_spins(owned[(i + 1) % nslab][:ghost], row_first=per)
+    tot = np.sum([s.observables() for s in slabs], axis=0)
+    assert tuple(int(v) for v in tot) == ora.ising2d_observables(want, periodic)
+
+
+# ----------------------------------------------------------------------------- K2 dense sweep
+@pytest.mark.parametrize("n", [1, 12, 64, 65, 200])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_dense_sweep_matches_oracle(hip, n, dtype):
+    rng = np.random.default_rng(n)
+    J = rng.normal(size=(n, n)) / max(1.0, np.sqrt(n))
+    if n % 2 == 0:
+        J = (J + J.T) / 2  # symmetric for even n, asymmetric for odd n (exercises the J^T path)
+    if dtype == "f32":
+        J = J.astype(np.float32).astype(np.float64)
+    b = rng.normal(size=n) * 0.3
+    st = rng.integers(0, 2, size=n).astype(np.int8)
+    T, seed = 0.9, 4242
+    d = hip.DenseSystem(J, b, hip.DTYPE_F64 if dtype == "f64" else hip.DTYPE_F32)
+    # Philox uniforms, natural order
+    d.set_state(st)
+    d.sweep(T, 5, seed=seed, sweep0=2)
+    want = ora.dense_sweep_philox(st, J, b, T, 5, seed, sweep0=2)
+    np.testing.assert_array_equal(d.get_state(), want)
+    assert abs(d.energy() - ora.c_dense_energy(want, J, b)) < 1e-9 * max(1.0, n)
+    # replayed uniforms + permuted order (the reference's update_order="random")
+    order = np.array([rng.permutation(n) for _ in range(4)])
+    u = rng.random(size=(4, n))
+    d.set_state(st)
+    d.sweep(T, 4, order=order, replay_uniforms=u)
+    want = ora.c_dense_sweep_replay(st, J, b, T, u, order)
+    np.testing.assert_array_equal(d.get_state().astype(np.int64), want)
+
+
+def test_dense_golden_replay_on_device(hip, golden):
+    """The reference's own seeded run (tests/golden/g1, g2) reproduced by the HIP kernel with replayed MT19937 draws."""
+    for name in ("g1_dense_sequential", "g2_dense_random"):
+        g = golden(name)
+        order = g["perms"] if name.startswith("g2") else None
+        d = hip.DenseSystem(g["J"], g["bias"])
+        d.set_state(g["init"].astype(np.int8))
+        T, burnin, ns = float(g["T"]), int(g["burnin"]), int(g["n_sweeps"])
+        d.sweep(T, burnin, order=None if order is None else order[:burnin], replay_uniforms=g["uniforms"][:burnin])
+        pos = burnin
+        for k in range(int(g["n_samples"])):
+            d.sweep(T, ns, order=None if order is None else order[pos:pos + ns], replay_uniforms=g["uniforms"][pos:pos + ns])
+            pos += ns
+            np.testing.assert_array_equal(d.get_state(), g["samples"][k])
+
+
+# ----------------------------------------------------------------------------- K3 Langevin
+LANGEVIN_ATOL = 2e-4  # fp32; device log2/sin/cos are the native approximations (v_log_f32, v_sin_f32, v_cos_f32)
+
+
+@pytest.mark.parametrize("n_chains,dim", [(1, 8), (3, 64), (2, 1027), (1, 5)])
+def test_langevin_matches_oracle(hip, n_chains, dim):
+    rng = np.random.default_rng(dim)
+    x = rng.normal(size=(n_chains, dim)).astype(np.float32)
+    k = rng.uniform(0.5, 2.0, size=dim).astype(np.float32)
+    mu = rng.normal(size=dim).astype(np.float32)
+    T, dt, gamma, seed = 0.7, 0.02, 1.5, 99
+    lc = hip.LangevinChains(n_chains, dim)
+    lc.set_energy(k, mu)
+    lc.set_state(x)
+    traj = lc.step(20, dt, gamma, T, seed, step0=3, chain0=5, trajectory=True)
+    want, wtraj = ora.langevin_quadratic_f32(x, k, mu, 20, dt, gamma, T, seed, step0=3, chain0=5, trajectory=True)
+    np.testing.assert_allclose(traj, wtraj, rtol=0, atol=LANGEVIN_ATOL)
+    np.testing.assert_allclose(lc.get_state(), want, rtol=0, atol=LANGEVIN_ATOL)
+    # one launch per step == fused steps (same counters)
+    lc.set_state(x)
+    lc.set_kernel(steps_per_launch=1)
+    lc.step(20, dt, gamma, T, seed, step0=3, chain0=5)
+    np.testing.assert_array_equal(lc.get_state(), traj[-1])
+    # restart: x_init + amp * N(0,1)
+    lc.restart(mu, 0.1, seed, chain0=2)
+    wantr = np.array([[mu[i] + np.float32(0.1) * ora.langevin_normals_f32(i >> 2, 2 + c, 0, seed, ora.TAG_LANGEVIN_RESTART)[i & 3]
+                       for i in range(dim)] for c in range(n_chains)], dtype=np.float32)
+    np.testing.assert_allclose(lc.get_state(), wantr, rtol=0, atol=LANGEVIN_ATOL)
+
+
+def test_langevin_stationary_variance(hip):
+    """dim 2^16 chains-as-elements: var -> T / (k (1 - k dt / (2 gamma))) = 0.505051 for k=2, dt=0.01."""
+    lc = hip.LangevinChains(1, 1 << 16)
+    lc.set_energy(2.0, 0.0)
+    lc.set_state(np.zeros((1, 1 << 16), np.float32))
+    lc.step(1500, 0.01, 1.0, 1.0, 7)
+    x = lc.get_state()
+    assert abs(x.var() - 0.505051) < 0.01 and abs(x.mean()) < 0.02

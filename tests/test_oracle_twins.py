@@ -48,7 +48,7 @@ def test_lazy_uniform_equals_plain(rows, cols, periodic):
     spins = ora.ising2d_randomize(rows, cols, seed)
     # thresholds whose top 16 bits are hit often: force ties by using coarse tables
     for table in (ora.ising2d_thresholds(1.0, 0.0, 2.269185, 0),
-                  np.array([(k * 0x1111) << 16 | 0x8000 for k in range(25)], dtype=np.uint64),
+                  np.array([(k * 0x0A3D) << 16 | 0x8000 for k in range(25)], dtype=np.uint64),
                   np.array([0, 1 << 32, 1, (1 << 32) - 1, 65536] * 5, dtype=np.uint64)):
         a = ora.ising2d_sweep(spins, periodic, table, 4, seed, sweep0=7)
         b = ora.ising2d_sweep(spins, periodic, table, 4, seed, sweep0=7, plain=True)

@@ -1,0 +1,337 @@
+// dense.hip -- K2 sequential single-site heat-bath Gibbs on a dense coupling matrix (gfx950).
+//
+// Replaces GibbsSampler.gibbs_sweep on a dense J (tsu/gibbs.py:128-162): for every site in visiting
+// order h_i = J[i,:].s + b_i (INCLUDING J_ii s_i, gibbs.py:97), p = sigmoid(h_i/T) with the +-20 clamp
+// (gibbs.py:73-77), s_i <- (u < p) (gibbs.py:126).  The visiting order is the reference's (range(n) or
+// the caller's permutation); what is parallel is the arithmetic, not the Markov chain.
+//
+// Per sweep:
+//   1. field f = J s + b for all sites: one streaming pass over J (the HBM-bound part, N^2 * sizeof(J)).
+//   2. the visiting order is cut into blocks of 64 positions.  For each block one wave
+//        - gathers the 64 x 64 sub-block of J into LDS,
+//        - resolves the 64 sites in order: a lane's pending decision only changes when an earlier site of
+//          the block actually flips, so the wave jumps from flip to flip (ballot + ffs) instead of walking
+//          all 64 sites; each flip applies its column of the sub-block to the 64 fields;
+//      then a grid-wide kernel applies the block's flips to the fields of every site outside the block
+//      (f_j += sum_i delta_i J[j, i], read as rows of J^T so that the access is coalesced).
+//
+// Uniforms: replayed doubles from the host (bit-exact replay of np.random.rand) or Philox doubles keyed by
+// (site, sweep): a = W[2(i&1)] >> 5, b = W[2(i&1)+1] >> 6, u = (a 2^26 + b) / 2^53 with
+// W = Philox4x32-10(ctr = (i >> 1, 0, sweep, TAG_DENSE | replica << 8), key = seed).
+#include "tsu_common.h"
+
+#define DB 64  // block of visiting-order positions resolved by one wave
+
+struct tsu_dense {
+    tsu_ctx* ctx;
+    int n, dtype;
+    void* J;    // n x n row-major, f64 or f32
+    void* JT;   // transpose (aliases J when J is symmetric)
+    double* bias;
+    int8_t* state;
+    double* field;
+    int* flips;      // per block: [0] = count, [1..DB] = site, delta pairs packed (site << 1 | (delta > 0))
+    int64_t* order;  // device copy of the visiting order (n_sweeps * n) or NULL
+    double* uniforms;
+    size_t order_cap, uni_cap;
+    double* d_energy;
+};
+
+template <typename TJ>
+__global__ __launch_bounds__(256) void k2_matvec(const TJ* __restrict__ J, const int8_t* __restrict__ s,
+                                                const double* __restrict__ bias, double* __restrict__ f, int n) {
+    // one wave per row; lanes stride the row
+    int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= n) return;
+    const TJ* row = J + (size_t)wave * n;
+    double acc = 0.0;
+    for (int j = lane; j < n; j += 64) acc += (double)row[j] * (double)s[j];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) f[wave] = acc + (bias ? bias[wave] : 0.0);
+}
+
+static __device__ __forceinline__ double dense_uniform(uint32_t i, uint32_t t, uint32_t tag, uint32_t k0, uint32_t k1) {
+    u32x4 w = tsu_philox(i >> 1, 0u, t, tag, k0, k1);
+    uint32_t a = (i & 1) ? w.z : w.x, b = (i & 1) ? w.w : w.y;
+    a >>= 5;
+    b >>= 6;
+    return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+}
+
+static __device__ __forceinline__ double sigmoid_clamped(double x) {
+    if (x > 20.0) return 1.0;
+    if (x < -20.0) return 0.0;
+    return 1.0 / (1.0 + exp(-x));
+}
+
+// one wave resolves positions [pos0, pos0 + cnt) of the visiting order
+template <typename TJ>
+__global__ __launch_bounds__(64) void k2_resolve(const TJ* __restrict__ J, int8_t* __restrict__ s, double* __restrict__ f,
+                                                const int64_t* __restrict__ order, const double* __restrict__ uniforms,
+                                                int* __restrict__ flips, int n, int pos0, int cnt, double T, uint32_t sweep,
+                                                uint32_t tag, uint32_t k0, uint32_t k1) {
+    __shared__ double sub[DB][DB + 1];  // sub[i][k] = J[site_k][site_i]
+    __shared__ int sites[DB];
+    int lane = threadIdx.x;
+    int site = -1;
+    if (lane < cnt) site = order ? (int)order[pos0 + lane] : pos0 + lane;
+    sites[lane] = site;
+    __syncthreads();
+    for (int i = 0; i < cnt; ++i) {
+        int si = sites[i];
+        if (lane < cnt) sub[i][lane] = (double)J[(size_t)site * n + si];
+    }
+    __syncthreads();
+    double fk = 0.0, u = 2.0;
+    int bit = 0;
+    if (lane < cnt) {
+        fk = f[site];
+        bit = s[site];
+        u = uniforms ? uniforms[pos0 + lane] : dense_uniform((uint32_t)site, sweep, tag, k0, k1);
+    }
+    int nflip = 0;
+    int cursor = 0;
+    while (true) {
+        int cand = (lane < cnt && u < sigmoid_clamped(fk / T)) ? 1 : 0;
+        unsigned long long want = __ballot((lane >= cursor) && (lane < cnt) && (cand != bit));
+        if (want == 0ull) break;
+        int i = __ffsll((long long)want) - 1;  // first position at or after the cursor whose decision is a flip
+        int delta = __shfl(cand - bit, i, 64);
+        if (lane == i) bit = cand;
+        if (lane < cnt) fk += (double)delta * sub[i][lane];
+        if (lane == 0) flips[1 + nflip] = (sites[i] << 1) | (delta > 0 ? 1 : 0);
+        ++nflip;
+        cursor = i + 1;
+    }
+    if (lane < cnt) {
+        s[site] = (int8_t)bit;
+        f[site] = fk;
+    }
+    if (lane == 0) flips[0] = nflip;
+}
+
+// f_j += sum over the block's flips delta_i * J[j, i] for every site j NOT in the block (the block's own
+// fields were updated during the resolve).  Reads rows of J^T: JT[i, j] = J[j, i].
+template <typename TJ>
+__global__ __launch_bounds__(256) void k2_propagate(const TJ* __restrict__ JT, double* __restrict__ f,
+                                                   const int* __restrict__ flips, const int64_t* __restrict__ order,
+                                                   int n, int pos0, int cnt) {
+    __shared__ int sh_sites[DB];
+    __shared__ int sh_flips[DB + 1];
+    int nflip = flips[0];
+    if (nflip == 0) return;
+    if (threadIdx.x < cnt) sh_sites[threadIdx.x] = order ? (int)order[pos0 + threadIdx.x] : pos0 + threadIdx.x;
+    if (threadIdx.x < nflip) sh_flips[threadIdx.x] = flips[1 + threadIdx.x];
+    __syncthreads();
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    bool inside = false;
+    if (!order) inside = (j >= pos0 && j < pos0 + cnt);
+    else
+        for (int k = 0; k < cnt; ++k) inside |= (sh_sites[k] == j);
+    if (inside) return;
+    double acc = 0.0;
+    for (int k = 0; k < nflip; ++k) {
+        int v = sh_flips[k];
+        double d = (v & 1) ? 1.0 : -1.0;
+        acc += d * (double)JT[(size_t)(v >> 1) * n + j];
+    }
+    f[j] += acc;
+}
+
+__global__ __launch_bounds__(256) void k2_energy(const double* __restrict__ f, const int8_t* __restrict__ s,
+                                                const double* __restrict__ bias, double* __restrict__ out, int n) {
+    // f = J s + b  =>  -1/2 s.(f - b) - b.s
+    __shared__ double part[4];
+    double acc = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        double b = bias ? bias[i] : 0.0, si = (double)s[i];
+        acc += -0.5 * si * (f[i] - b) - b * si;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+template <typename TJ>
+static int dense_sweep_impl(tsu_dense* d, double T, int n_sweeps, bool have_order, uint64_t seed, uint32_t sweep0,
+                            uint32_t replica, bool have_uni) {
+    tsu_ctx* ctx = d->ctx;
+    const TJ* J = (const TJ*)d->J;
+    const TJ* JT = (const TJ*)d->JT;
+    int n = d->n;
+    uint32_t tag = TSU_TAG_DENSE | (replica << 8);
+    unsigned mv_grid = (unsigned)(((size_t)n * 64 + 255) / 256), pg_grid = (unsigned)((n + 255) / 256);
+    for (int s = 0; s < n_sweeps; ++s) {
+        k2_matvec<TJ><<<mv_grid, 256, 0, ctx->stream>>>(J, d->state, d->bias, d->field, n);
+        const int64_t* ord = have_order ? d->order + (size_t)s * n : nullptr;
+        const double* uni = have_uni ? d->uniforms + (size_t)s * n : nullptr;
+        for (int pos0 = 0; pos0 < n; pos0 += DB) {
+            int cnt = n - pos0 < DB ? n - pos0 : DB;
+            k2_resolve<TJ><<<1, 64, 0, ctx->stream>>>(J, d->state, d->field, ord, uni ? uni : nullptr, d->flips, n, pos0, cnt,
+                                                      T, sweep0 + (uint32_t)s, tag, (uint32_t)seed, (uint32_t)(seed >> 32));
+            if (pos0 + cnt < n)
+                k2_propagate<TJ><<<pg_grid, 256, 0, ctx->stream>>>(JT, d->field, d->flips, ord, n, pos0, cnt);
+        }
+    }
+    TSU_HIP_TRY(ctx, hipGetLastError());
+    return TSU_OK;
+}
+
+extern "C" {
+
+int tsu_dense_create(tsu_ctx* ctx, int n, const void* J_host, int dtype, const double* bias_host, tsu_dense** out) {
+    if (!ctx || !out) return TSU_E_INVALID;
+    *out = nullptr;
+    TSU_REQUIRE(ctx, n >= 1 && J_host, "Coupling matrix must be square");
+    TSU_REQUIRE(ctx, dtype == TSU_DTYPE_F64 || dtype == TSU_DTYPE_F32, "dense_create: bad dtype %d", dtype);
+    tsu_dense* d = new (std::nothrow) tsu_dense();
+    if (!d) return tsu_fail(ctx, TSU_E_NOMEM, "dense_create: host allocation failed");
+    memset(d, 0, sizeof(*d));
+    d->ctx = ctx;
+    d->n = n;
+    d->dtype = dtype;
+    size_t esz = dtype == TSU_DTYPE_F64 ? 8 : 4, jb = (size_t)n * n * esz;
+    // symmetric J: J^T aliases J; otherwise keep a transposed copy for the coalesced propagate pass
+    bool sym = true;
+    if (dtype == TSU_DTYPE_F64) {
+        const double* A = (const double*)J_host;
+        for (int i = 0; i < n && sym; ++i)
+            for (int j = i + 1; j < n; ++j)
+                if (A[(size_t)i * n + j] != A[(size_t)j * n + i]) { sym = false; break; }
+    } else {
+        const float* A = (const float*)J_host;
+        for (int i = 0; i < n && sym; ++i)
+            for (int j = i + 1; j < n; ++j)
+                if (A[(size_t)i * n + j] != A[(size_t)j * n + i]) { sym = false; break; }
+    }
+    hipError_t e = hipMalloc(&d->J, jb);
+    if (e == hipSuccess) e = hipMemcpyAsync(d->J, J_host, jb, hipMemcpyHostToDevice, ctx->stream);
+    void* hostT = nullptr;
+    if (e == hipSuccess && !sym) {
+        hostT = malloc(jb);
+        if (!hostT) e = hipErrorOutOfMemory;
+        else {
+            if (dtype == TSU_DTYPE_F64) {
+                const double* A = (const double*)J_host; double* B = (double*)hostT;
+                for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) B[(size_t)j * n + i] = A[(size_t)i * n + j];
+            } else {
+                const float* A = (const float*)J_host; float* B = (float*)hostT;
+                for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) B[(size_t)j * n + i] = A[(size_t)i * n + j];
+            }
+            e = hipMalloc(&d->JT, jb);
+            if (e == hipSuccess) e = hipMemcpyAsync(d->JT, hostT, jb, hipMemcpyHostToDevice, ctx->stream);
+        }
+    } else if (e == hipSuccess) {
+        d->JT = d->J;
+    }
+    if (e == hipSuccess && bias_host) {
+        e = hipMalloc(&d->bias, (size_t)n * 8);
+        if (e == hipSuccess) e = hipMemcpyAsync(d->bias, bias_host, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipMalloc(&d->state, (size_t)n);
+    if (e == hipSuccess) e = hipMemsetAsync(d->state, 0, (size_t)n, ctx->stream);
+    if (e == hipSuccess) e = hipMalloc(&d->field, (size_t)n * 8);
+    if (e == hipSuccess) e = hipMalloc(&d->flips, (DB + 1) * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&d->d_energy, 8);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (hostT) free(hostT);
+    if (e != hipSuccess) {
+        int rc = tsu_fail(ctx, e == hipErrorOutOfMemory ? TSU_E_NOMEM : TSU_E_HIP, "dense_create: %s", hipGetErrorString(e));
+        tsu_dense_destroy(d);
+        return rc;
+    }
+    *out = d;
+    return TSU_OK;
+}
+
+int tsu_dense_destroy(tsu_dense* d) {
+    if (!d) return TSU_OK;
+    (void)hipStreamSynchronize(d->ctx->stream);
+    if (d->JT && d->JT != d->J) (void)hipFree(d->JT);
+    if (d->J) (void)hipFree(d->J);
+    if (d->bias) (void)hipFree(d->bias);
+    if (d->state) (void)hipFree(d->state);
+    if (d->field) (void)hipFree(d->field);
+    if (d->flips) (void)hipFree(d->flips);
+    if (d->order) (void)hipFree(d->order);
+    if (d->uniforms) (void)hipFree(d->uniforms);
+    if (d->d_energy) (void)hipFree(d->d_energy);
+    delete d;
+    return TSU_OK;
+}
+
+int tsu_dense_set_state(tsu_dense* d, const int8_t* bits_host) {
+    if (!d) return TSU_E_INVALID;
+    TSU_REQUIRE(d->ctx, bits_host != nullptr, "dense_set_state: NULL");
+    for (int i = 0; i < d->n; ++i) TSU_REQUIRE(d->ctx, bits_host[i] == 0 || bits_host[i] == 1, "dense_set_state: state must be 0/1");
+    TSU_HIP_TRY(d->ctx, hipMemcpyAsync(d->state, bits_host, (size_t)d->n, hipMemcpyHostToDevice, d->ctx->stream));
+    TSU_HIP_TRY(d->ctx, hipStreamSynchronize(d->ctx->stream));
+    return TSU_OK;
+}
+
+int tsu_dense_get_state(tsu_dense* d, int8_t* bits_host) {
+    if (!d) return TSU_E_INVALID;
+    TSU_REQUIRE(d->ctx, bits_host != nullptr, "dense_get_state: NULL");
+    TSU_HIP_TRY(d->ctx, hipMemcpyAsync(bits_host, d->state, (size_t)d->n, hipMemcpyDeviceToHost, d->ctx->stream));
+    TSU_HIP_TRY(d->ctx, hipStreamSynchronize(d->ctx->stream));
+    return TSU_OK;
+}
+
+int tsu_dense_sweep(tsu_dense* d, double T, int n_sweeps, const int64_t* order, uint64_t seed, uint32_t sweep0,
+                    uint32_t replica, const double* replay_uniforms) {
+    if (!d) return TSU_E_INVALID;
+    tsu_ctx* ctx = d->ctx;
+    TSU_REQUIRE(ctx, T > 0.0, "Temperature must be positive");
+    TSU_REQUIRE(ctx, n_sweeps >= 0, "dense_sweep: n_sweeps must be >= 0");
+    if (n_sweeps == 0) return TSU_OK;
+    size_t cnt = (size_t)n_sweeps * d->n;
+    if (order) {
+        for (size_t i = 0; i < cnt; ++i)
+            TSU_REQUIRE(ctx, order[i] >= 0 && order[i] < d->n, "dense_sweep: order[%zu] = %lld out of range", i, (long long)order[i]);
+        if (d->order_cap < cnt) {
+            if (d->order) (void)hipFree(d->order);
+            d->order = nullptr;
+            d->order_cap = 0;
+            TSU_HIP_TRY(ctx, hipMalloc(&d->order, cnt * 8));
+            d->order_cap = cnt;
+        }
+        TSU_HIP_TRY(ctx, hipMemcpyAsync(d->order, order, cnt * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (replay_uniforms) {
+        if (d->uni_cap < cnt) {
+            if (d->uniforms) (void)hipFree(d->uniforms);
+            d->uniforms = nullptr;
+            d->uni_cap = 0;
+            TSU_HIP_TRY(ctx, hipMalloc(&d->uniforms, cnt * 8));
+            d->uni_cap = cnt;
+        }
+        TSU_HIP_TRY(ctx, hipMemcpyAsync(d->uniforms, replay_uniforms, cnt * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (order || replay_uniforms) TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host buffers are the caller's
+    if (d->dtype == TSU_DTYPE_F64)
+        return dense_sweep_impl<double>(d, T, n_sweeps, order != nullptr, seed, sweep0, replica, replay_uniforms != nullptr);
+    return dense_sweep_impl<float>(d, T, n_sweeps, order != nullptr, seed, sweep0, replica, replay_uniforms != nullptr);
+}
+
+int tsu_dense_energy(tsu_dense* d, double* energy) {
+    if (!d) return TSU_E_INVALID;
+    tsu_ctx* ctx = d->ctx;
+    TSU_REQUIRE(ctx, energy != nullptr, "dense_energy: NULL");
+    unsigned mv_grid = (unsigned)(((size_t)d->n * 64 + 255) / 256);
+    if (d->dtype == TSU_DTYPE_F64)
+        k2_matvec<double><<<mv_grid, 256, 0, ctx->stream>>>((const double*)d->J, d->state, d->bias, d->field, d->n);
+    else
+        k2_matvec<float><<<mv_grid, 256, 0, ctx->stream>>>((const float*)d->J, d->state, d->bias, d->field, d->n);
+    TSU_HIP_TRY(ctx, hipMemsetAsync(d->d_energy, 0, 8, ctx->stream));
+    int blocks = (d->n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    k2_energy<<<blocks, 256, 0, ctx->stream>>>(d->field, d->state, d->bias, d->d_energy, d->n);
+    TSU_HIP_TRY(ctx, hipGetLastError());
+    TSU_HIP_TRY(ctx, hipMemcpyAsync(energy, d->d_energy, 8, hipMemcpyDeviceToHost, ctx->stream));
+    TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TSU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,27 @@
+// ising2d.h -- lattice handle shared by ising2d.hip (generic kernel, K4, host API) and ising2d_tiled.hip.
+#pragma once
+#include "tsu_common.h"
+
+struct tsu_ising2d {
+    tsu_ctx* ctx;
+    int64_t total_rows;  // global lattice height
+    int64_t row0;        // global index of owned row 0
+    int rows, cols;      // owned rows, columns
+    int periodic;
+    int ghost;           // ghost rows on each side (0 for a whole lattice)
+    int wrap_rows;       // whole periodic lattice on one GPU: vertical neighbours wrap inside the buffer
+    size_t pitch;
+    int8_t* alloc[2];    // ping-pong buffers (second one allocated on first tiled launch)
+    int cur;
+    uint64_t table[25];
+    int have_table;
+    int kernel, sweeps_per_launch;
+    int64_t* d_obs;      // 2 x int64 accumulators
+    hipEvent_t ev0, ev1;
+    int timed;
+};
+
+
+// ising2d_tiled.hip
+int tsu_ising2d_tiled_supported(const tsu_ising2d* L);
+int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_t sweep0, uint32_t replica);

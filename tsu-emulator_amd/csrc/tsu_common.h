@@ -1,0 +1,71 @@
+// tsu_common.h -- shared internals of libtsu_hip.so (gfx950 only; no CUDA/HIP dual paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/tsu_hip.h"
+
+struct tsu_ctx {
+    int device;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+    char err[512];
+    int cus;
+};
+
+extern thread_local char g_tsu_init_err[512];
+
+int tsu_fail(tsu_ctx* ctx, int code, const char* fmt, ...);
+
+#define TSU_HIP_TRY(ctx, expr)                                                                      \
+    do {                                                                                            \
+        hipError_t e__ = (expr);                                                                    \
+        if (e__ != hipSuccess)                                                                      \
+            return tsu_fail((ctx), e__ == hipErrorOutOfMemory ? TSU_E_NOMEM : TSU_E_HIP, "%s: %s (%s:%d)", #expr, \
+                            hipGetErrorString(e__), __FILE__, __LINE__);                            \
+    } while (0)
+
+#define TSU_REQUIRE(ctx, cond, ...)                                   \
+    do {                                                              \
+        if (!(cond)) return tsu_fail((ctx), TSU_E_INVALID, __VA_ARGS__); \
+    } while (0)
+
+// ------------------------------------------------------------------ Philox4x32-10 (device + host)
+#define TSU_PHILOX_M0 0xD2511F53u
+#define TSU_PHILOX_M1 0xCD9E8D57u
+#define TSU_PHILOX_W0 0x9E3779B9u
+#define TSU_PHILOX_W1 0xBB67AE85u
+
+// ctr[3] stream tags (low byte); bits 8.. carry the replica / chain-group id.  DESIGN.md "RNG stream contract".
+enum : uint32_t {
+    TSU_TAG_ISING_HI = 0,
+    TSU_TAG_ISING_LO = 1,
+    TSU_TAG_INIT = 2,
+    TSU_TAG_LANGEVIN = 3,
+    TSU_TAG_DENSE = 4,
+    TSU_TAG_LANGEVIN_RESTART = 5
+};
+
+struct u32x4 {
+    uint32_t x, y, z, w;
+};
+
+__host__ __device__ __forceinline__ u32x4 tsu_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                     uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)TSU_PHILOX_M0 * c0;
+        uint64_t p1 = (uint64_t)TSU_PHILOX_M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += TSU_PHILOX_W0;
+        k1 += TSU_PHILOX_W1;
+    }
+    return u32x4{c0, c1, c2, c3};
+}

@@ -1,0 +1,140 @@
+// tsu_ctx.hip -- context, stream, timers, error text, device-side Philox known-answer entry point.
+#include <stdarg.h>
+
+#include "tsu_common.h"
+
+thread_local char g_tsu_init_err[512] = "";
+
+int tsu_fail(tsu_ctx* ctx, int code, const char* fmt, ...) {
+    char* dst = ctx ? ctx->err : g_tsu_init_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" {
+
+int tsu_version(void) { return 100; }
+
+int tsu_init(int device, tsu_ctx** out) {
+    if (!out) return tsu_fail(nullptr, TSU_E_INVALID, "tsu_init: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return tsu_fail(nullptr, TSU_E_HIP, "tsu_init: no HIP device available (%s); the HIP path has no CPU fallback",
+                        e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0) {
+        e = hipGetDevice(&device);
+        if (e != hipSuccess) return tsu_fail(nullptr, TSU_E_HIP, "hipGetDevice: %s", hipGetErrorString(e));
+    }
+    if (device >= count) return tsu_fail(nullptr, TSU_E_INVALID, "tsu_init: device %d out of range (%d)", device, count);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return tsu_fail(nullptr, TSU_E_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+    tsu_ctx* ctx = new (std::nothrow) tsu_ctx();
+    if (!ctx) return tsu_fail(nullptr, TSU_E_NOMEM, "tsu_init: host allocation failed");
+    ctx->device = device;
+    ctx->stream = nullptr;
+    ctx->err[0] = 0;
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) {
+        delete ctx;
+        return tsu_fail(nullptr, TSU_E_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    }
+    ctx->cus = prop.multiProcessorCount;
+    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx;
+        return tsu_fail(nullptr, TSU_E_HIP, "hipEventCreate failed");
+    }
+    *out = ctx;
+    return TSU_OK;
+}
+
+int tsu_shutdown(tsu_ctx* ctx) {
+    if (!ctx) return TSU_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipEventDestroy(ctx->ev0);
+    (void)hipEventDestroy(ctx->ev1);
+    delete ctx;
+    return TSU_OK;
+}
+
+const char* tsu_last_error(const tsu_ctx* ctx) { return ctx ? ctx->err : g_tsu_init_err; }
+
+int tsu_set_stream(tsu_ctx* ctx, void* hip_stream) {
+    if (!ctx) return TSU_E_INVALID;
+    ctx->stream = (hipStream_t)hip_stream;
+    return TSU_OK;
+}
+
+int tsu_synchronize(tsu_ctx* ctx) {
+    if (!ctx) return TSU_E_INVALID;
+    TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TSU_OK;
+}
+
+int tsu_device_info(tsu_ctx* ctx, char* name, int name_len, int* compute_units, uint64_t* hbm_bytes) {
+    if (!ctx) return TSU_E_INVALID;
+    hipDeviceProp_t prop;
+    TSU_HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (uint64_t)prop.totalGlobalMem;
+    return TSU_OK;
+}
+
+int tsu_timer_begin(tsu_ctx* ctx) {
+    if (!ctx) return TSU_E_INVALID;
+    TSU_HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return TSU_OK;
+}
+
+int tsu_timer_end(tsu_ctx* ctx, float* elapsed_ms) {
+    if (!ctx || !elapsed_ms) return TSU_E_INVALID;
+    TSU_HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    TSU_HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+    TSU_HIP_TRY(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    return TSU_OK;
+}
+
+}  // extern "C"
+
+__global__ void philox_kat_kernel(int n, const uint32_t* __restrict__ ctrs, uint32_t k0, uint32_t k1,
+                                  uint32_t* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32x4 r = tsu_philox(ctrs[4 * i], ctrs[4 * i + 1], ctrs[4 * i + 2], ctrs[4 * i + 3], k0, k1);
+    out[4 * i] = r.x;
+    out[4 * i + 1] = r.y;
+    out[4 * i + 2] = r.z;
+    out[4 * i + 3] = r.w;
+}
+
+extern "C" int tsu_philox4x32_10(tsu_ctx* ctx, int n, const uint32_t* ctrs, const uint32_t* key, uint32_t* out) {
+    if (!ctx) return TSU_E_INVALID;
+    TSU_REQUIRE(ctx, n > 0 && ctrs && key && out, "tsu_philox4x32_10: bad arguments");
+    uint32_t *d_in = nullptr, *d_out = nullptr;
+    size_t bytes = (size_t)n * 4 * sizeof(uint32_t);
+    TSU_HIP_TRY(ctx, hipMalloc(&d_in, bytes));
+    hipError_t e = hipMalloc(&d_out, bytes);
+    if (e != hipSuccess) {
+        (void)hipFree(d_in);
+        return tsu_fail(ctx, TSU_E_NOMEM, "hipMalloc: %s", hipGetErrorString(e));
+    }
+    int rc = TSU_OK;
+    do {
+        if ((e = hipMemcpyAsync(d_in, ctrs, bytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+        philox_kat_kernel<<<(n + 255) / 256, 256, 0, ctx->stream>>>(n, d_in, key[0], key[1], d_out);
+        if ((e = hipGetLastError()) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+        e = hipStreamSynchronize(ctx->stream);
+    } while (0);
+    if (e != hipSuccess) rc = tsu_fail(ctx, TSU_E_HIP, "tsu_philox4x32_10: %s", hipGetErrorString(e));
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return rc;
+}

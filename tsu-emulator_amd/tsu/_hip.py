@@ -1,0 +1,352 @@
+"""ctypes binding of libtsu_hip.so (include/tsu_hip.h) -- the only door to the GPU.
+
+There is deliberately no CPU fallback in this package: if the HIP library is missing or no GPU is
+present, every operation that needs it raises :class:`HipUnavailableError`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libtsu_hip.so")
+
+TSU_OK = 0
+TSU_E_INVALID, TSU_E_NOMEM, TSU_E_HIP, TSU_E_RCCL, TSU_E_UNSUPPORTED = -1, -2, -3, -4, -5
+MODE_PHYSICAL, MODE_COMPAT = 0, 1
+DTYPE_F64, DTYPE_F32 = 0, 1
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_TILED = 0, 1, 2
+
+
+class HipUnavailableError(RuntimeError):
+    """libtsu_hip.so is not built / not loadable, or there is no HIP device."""
+
+
+class HipError(RuntimeError):
+    """A call into libtsu_hip.so failed (TSU_E_HIP / TSU_E_NOMEM / TSU_E_RCCL)."""
+
+
+class UnsupportedError(HipError):
+    """TSU_E_UNSUPPORTED: valid request the HIP build has no kernel for."""
+
+
+_u8p, _i8p = C.POINTER(C.c_uint8), C.POINTER(C.c_int8)
+_u32p, _u64p, _i64p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_int64)
+_f32p, _f64p = C.POINTER(C.c_float), C.POINTER(C.c_double)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes): mirrors include/tsu_hip.h one to one (tests check every symbol exists)
+SIGNATURES = {
+    "tsu_version": (C.c_int, []),
+    "tsu_init": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "tsu_shutdown": (C.c_int, [_vp]),
+    "tsu_last_error": (C.c_char_p, [_vp]),
+    "tsu_set_stream": (C.c_int, [_vp, _vp]),
+    "tsu_synchronize": (C.c_int, [_vp]),
+    "tsu_device_info": (C.c_int, [_vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), _u64p]),
+    "tsu_timer_begin": (C.c_int, [_vp]),
+    "tsu_timer_end": (C.c_int, [_vp, _f32p]),
+    "tsu_philox4x32_10": (C.c_int, [_vp, C.c_int, _u32p, _u32p, _u32p]),
+    "tsu_ising2d_thresholds": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_int, _u64p]),
+    "tsu_ising2d_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "tsu_ising2d_create_slab": (C.c_int, [_vp, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int,
+                                          C.POINTER(_vp)]),
+    "tsu_ising2d_destroy": (C.c_int, [_vp]),
+    "tsu_ising2d_set_spins": (C.c_int, [_vp, _i8p, C.c_int, C.c_int]),
+    "tsu_ising2d_get_spins": (C.c_int, [_vp, _i8p, C.c_int, C.c_int]),
+    "tsu_ising2d_randomize": (C.c_int, [_vp, C.c_uint64, C.c_uint32]),
+    "tsu_ising2d_fill": (C.c_int, [_vp, C.c_int8]),
+    "tsu_ising2d_set_thresholds": (C.c_int, [_vp, _u64p]),
+    "tsu_ising2d_set_model": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double, C.c_int]),
+    "tsu_ising2d_set_kernel": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "tsu_ising2d_sweep": (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32]),
+    "tsu_ising2d_observables": (C.c_int, [_vp, _i64p, _i64p]),
+    "tsu_ising2d_row_ptr": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "tsu_ising2d_last_sweep_ms": (C.c_int, [_vp, _f32p]),
+    "tsu_dense_create": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _f64p, C.POINTER(_vp)]),
+    "tsu_dense_destroy": (C.c_int, [_vp]),
+    "tsu_dense_set_state": (C.c_int, [_vp, _i8p]),
+    "tsu_dense_get_state": (C.c_int, [_vp, _i8p]),
+    "tsu_dense_sweep": (C.c_int, [_vp, C.c_double, C.c_int, _i64p, C.c_uint64, C.c_uint32, C.c_uint32, _f64p]),
+    "tsu_dense_energy": (C.c_int, [_vp, _f64p]),
+    "tsu_langevin_create": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "tsu_langevin_destroy": (C.c_int, [_vp]),
+    "tsu_langevin_set_state": (C.c_int, [_vp, _f32p]),
+    "tsu_langevin_get_state": (C.c_int, [_vp, _f32p]),
+    "tsu_langevin_set_energy": (C.c_int, [_vp, _f32p, _f32p]),
+    "tsu_langevin_restart": (C.c_int, [_vp, _f32p, C.c_float, C.c_uint64, C.c_uint32]),
+    "tsu_langevin_step": (C.c_int, [_vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_uint32,
+                                    C.c_uint32, _f32p]),
+    "tsu_langevin_set_kernel": (C.c_int, [_vp, C.c_int]),
+}
+
+_lib = None
+
+
+def load_library():
+    """dlopen libtsu_hip.so and declare every prototype.  Raises HipUnavailableError if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipUnavailableError(
+            f"{LIB_PATH} not found: build it with tsu-emulator_amd/csrc/build.sh (hipcc, gfx950). "
+            "This package has no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # missing ROCm runtime etc.
+        raise HipUnavailableError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t)
+
+
+class Context:
+    """One tsu_ctx (one GPU).  ``Context.default()`` is the per-process singleton used by the API layer."""
+
+    _default = None
+
+    def __init__(self, device=-1):
+        self.lib = load_library()
+        h = _vp()
+        rc = self.lib.tsu_init(int(device), C.byref(h))
+        if rc != TSU_OK:
+            msg = self.lib.tsu_last_error(None).decode()
+            raise HipUnavailableError(f"tsu_init failed ({rc}): {msg}")
+        self.h = h
+
+    @classmethod
+    def default(cls):
+        if cls._default is None:
+            dev = int(os.environ.get("TSU_HIP_DEVICE", os.environ.get("LOCAL_RANK", "-1")))
+            cls._default = cls(dev)
+        return cls._default
+
+    def check(self, rc):
+        if rc == TSU_OK:
+            return
+        msg = self.lib.tsu_last_error(self.h).decode()
+        if rc == TSU_E_INVALID:
+            raise ValueError(msg)
+        if rc == TSU_E_UNSUPPORTED:
+            raise UnsupportedError(msg)
+        if rc == TSU_E_NOMEM:
+            raise MemoryError(msg)
+        raise HipError(f"libtsu_hip error {rc}: {msg}")
+
+    def set_stream(self, stream_ptr):
+        self.check(self.lib.tsu_set_stream(self.h, _vp(stream_ptr or 0)))
+
+    def synchronize(self):
+        self.check(self.lib.tsu_synchronize(self.h))
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus, mem = C.c_int(0), C.c_uint64(0)
+        self.check(self.lib.tsu_device_info(self.h, name, 256, C.byref(cus), C.byref(mem)))
+        return {"name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": mem.value}
+
+    def timer_begin(self):
+        self.check(self.lib.tsu_timer_begin(self.h))
+
+    def timer_end(self):
+        ms = C.c_float(0)
+        self.check(self.lib.tsu_timer_end(self.h, C.byref(ms)))
+        return ms.value
+
+    def philox4x32_10(self, ctrs, key):
+        ctrs = np.ascontiguousarray(ctrs, dtype=np.uint32).reshape(-1, 4)
+        key = np.ascontiguousarray(key, dtype=np.uint32).reshape(2)
+        out = np.zeros_like(ctrs)
+        self.check(self.lib.tsu_philox4x32_10(self.h, ctrs.shape[0], _ptr(ctrs, _u32p), _ptr(key, _u32p),
+                                              _ptr(out, _u32p)))
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.tsu_shutdown(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def ising2d_thresholds(J, h, T, mode=MODE_PHYSICAL):
+    """Host helper of the library (no GPU needed): table[deg*5+up] as uint64."""
+    lib = load_library()
+    t = np.zeros(25, dtype=np.uint64)
+    rc = lib.tsu_ising2d_thresholds(float(J), float(h), float(T), int(mode), _ptr(t, _u64p))
+    if rc != TSU_OK:
+        raise ValueError("Temperature must be positive" if not T > 0 else "invalid threshold arguments")
+    return t
+
+
+class Lattice:
+    """tsu_ising2d handle: a rows x cols lattice (or a row slab of one) of +-1 int8 spins on the GPU."""
+
+    def __init__(self, rows, cols, periodic=False, ctx=None, total_rows=None, row0=0, ghost=0):
+        self.ctx = ctx or Context.default()
+        self.lib = self.ctx.lib
+        self.rows, self.cols, self.periodic = int(rows), int(cols), bool(periodic)
+        self.total_rows = int(total_rows if total_rows is not None else rows)
+        self.row0, self.ghost = int(row0), int(ghost)
+        h = _vp()
+        self.ctx.check(self.lib.tsu_ising2d_create_slab(self.ctx.h, self.total_rows, self.cols, int(self.periodic),
+                                                        self.row0, self.rows, self.ghost, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tsu_ising2d_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_spins(self, spins, row_first=0):
+        s = np.ascontiguousarray(spins, dtype=np.int8).reshape(-1, self.cols)
+        self.ctx.check(self.lib.tsu_ising2d_set_spins(self.h, _ptr(s, _i8p), int(row_first), s.shape[0]))
+
+    def get_spins(self, row_first=0, n_rows=None):
+        n_rows = self.rows if n_rows is None else int(n_rows)
+        out = np.empty((n_rows, self.cols), dtype=np.int8)
+        self.ctx.check(self.lib.tsu_ising2d_get_spins(self.h, _ptr(out, _i8p), int(row_first), n_rows))
+        return out
+
+    def randomize(self, seed, replica=0):
+        self.ctx.check(self.lib.tsu_ising2d_randomize(self.h, int(seed), int(replica)))
+
+    def fill(self, value):
+        self.ctx.check(self.lib.tsu_ising2d_fill(self.h, int(value)))
+
+    def set_thresholds(self, table):
+        t = np.ascontiguousarray(table, dtype=np.uint64)
+        if t.size != 25:
+            raise ValueError("threshold table must have 25 entries")
+        self.ctx.check(self.lib.tsu_ising2d_set_thresholds(self.h, _ptr(t, _u64p)))
+
+    def set_model(self, J, h, T, mode=MODE_PHYSICAL):
+        self.ctx.check(self.lib.tsu_ising2d_set_model(self.h, float(J), float(h), float(T), int(mode)))
+
+    def set_kernel(self, kernel=KERNEL_AUTO, sweeps_per_launch=0):
+        self.ctx.check(self.lib.tsu_ising2d_set_kernel(self.h, int(kernel), int(sweeps_per_launch)))
+
+    def sweep(self, n_sweeps, seed, sweep0=0, replica=0):
+        self.ctx.check(self.lib.tsu_ising2d_sweep(self.h, int(n_sweeps), int(seed), int(sweep0), int(replica)))
+
+    def observables(self):
+        a, b = C.c_int64(0), C.c_int64(0)
+        self.ctx.check(self.lib.tsu_ising2d_observables(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def row_ptr(self, local_row):
+        p, pitch = _vp(), C.c_size_t(0)
+        self.ctx.check(self.lib.tsu_ising2d_row_ptr(self.h, int(local_row), C.byref(p), C.byref(pitch)))
+        return p.value, pitch.value
+
+    def last_sweep_ms(self):
+        ms = C.c_float(0)
+        self.ctx.check(self.lib.tsu_ising2d_last_sweep_ms(self.h, C.byref(ms)))
+        return ms.value
+
+
+class DenseSystem:
+    """tsu_dense handle: dense coupling matrix + bias resident on the GPU, {0,1} int8 state."""
+
+    def __init__(self, J, bias=None, dtype=DTYPE_F64, ctx=None):
+        self.ctx = ctx or Context.default()
+        self.lib = self.ctx.lib
+        J = np.asarray(J)
+        if J.ndim != 2 or J.shape[0] != J.shape[1]:
+            raise ValueError("Coupling matrix must be square")
+        self.n = J.shape[0]
+        Jc = np.ascontiguousarray(J, dtype=np.float64 if dtype == DTYPE_F64 else np.float32)
+        b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float64)
+        if b is not None and b.size != self.n:
+            raise ValueError(f"bias must have length {self.n}")
+        h = _vp()
+        self.ctx.check(self.lib.tsu_dense_create(self.ctx.h, self.n, Jc.ctypes.data_as(_vp), int(dtype),
+                                                 None if b is None else _ptr(b, _f64p), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tsu_dense_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_state(self, bits):
+        b = np.ascontiguousarray(bits, dtype=np.int8).reshape(self.n)
+        self.ctx.check(self.lib.tsu_dense_set_state(self.h, _ptr(b, _i8p)))
+
+    def get_state(self):
+        out = np.empty(self.n, dtype=np.int8)
+        self.ctx.check(self.lib.tsu_dense_get_state(self.h, _ptr(out, _i8p)))
+        return out
+
+    def sweep(self, T, n_sweeps, seed=0, sweep0=0, replica=0, order=None, replay_uniforms=None):
+        o = None if order is None else np.ascontiguousarray(order, dtype=np.int64).reshape(n_sweeps, self.n)
+        u = None if replay_uniforms is None else np.ascontiguousarray(replay_uniforms, dtype=np.float64).reshape(
+            n_sweeps, self.n)
+        self.ctx.check(self.lib.tsu_dense_sweep(self.h, float(T), int(n_sweeps), None if o is None else _ptr(o, _i64p),
+                                                int(seed), int(sweep0), int(replica),
+                                                None if u is None else _ptr(u, _f64p)))
+
+    def energy(self):
+        e = C.c_double(0)
+        self.ctx.check(self.lib.tsu_dense_energy(self.h, C.byref(e)))
+        return e.value
+
+
+class LangevinChains:
+    """tsu_langevin handle: n_chains x dim float32 states with a separable quadratic energy."""
+
+    def __init__(self, n_chains, dim, ctx=None):
+        self.ctx = ctx or Context.default()
+        self.lib = self.ctx.lib
+        self.n_chains, self.dim = int(n_chains), int(dim)
+        h = _vp()
+        self.ctx.check(self.lib.tsu_langevin_create(self.ctx.h, self.n_chains, self.dim, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tsu_langevin_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_state(self, x):
+        xx = np.ascontiguousarray(np.broadcast_to(np.asarray(x, dtype=np.float32), (self.n_chains, self.dim)))
+        self.ctx.check(self.lib.tsu_langevin_set_state(self.h, _ptr(xx, _f32p)))
+
+    def get_state(self):
+        out = np.empty((self.n_chains, self.dim), dtype=np.float32)
+        self.ctx.check(self.lib.tsu_langevin_get_state(self.h, _ptr(out, _f32p)))
+        return out
+
+    def set_energy(self, k, mu):
+        kk = np.ascontiguousarray(np.broadcast_to(np.asarray(k, dtype=np.float32), (self.dim,)))
+        mm = np.ascontiguousarray(np.broadcast_to(np.asarray(mu, dtype=np.float32), (self.dim,)))
+        self.ctx.check(self.lib.tsu_langevin_set_energy(self.h, _ptr(kk, _f32p), _ptr(mm, _f32p)))
+
+    def restart(self, x_init, amp, seed, chain0=0):
+        xi = np.ascontiguousarray(np.broadcast_to(np.asarray(x_init, dtype=np.float32), (self.dim,)))
+        self.ctx.check(self.lib.tsu_langevin_restart(self.h, _ptr(xi, _f32p), float(amp), int(seed), int(chain0)))
+
+    def step(self, n_steps, dt, gamma, T, seed, step0=0, chain0=0, trajectory=False):
+        traj = np.empty((n_steps, self.n_chains, self.dim), dtype=np.float32) if trajectory else None
+        self.ctx.check(self.lib.tsu_langevin_step(self.h, int(n_steps), float(dt), float(gamma), float(T), int(seed),
+                                                  int(step0), int(chain0),
+                                                  None if traj is None else _ptr(traj, _f32p)))
+        return traj
+
+    def set_kernel(self, steps_per_launch=0):
+        self.ctx.check(self.lib.tsu_langevin_set_kernel(self.h, int(steps_per_launch)))
