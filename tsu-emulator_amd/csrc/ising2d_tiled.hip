@@ -1,8 +1,312 @@
-// ising2d_tiled.hip -- K1 fast path: LDS-staged 2-D halo tiles, several sweeps per launch (gfx950).
-#include "tsu_common.h"
+// ising2d_tiled.hip -- K1 fast path: LDS-staged 2-D halo tiles, k full sweeps per launch (gfx950).
+//
+// Same Markov kernel and the same Philox stream as k1_generic / oracle ora_ising2d_sweep (results are bit
+// identical); what changes is the schedule:
+//   * a workgroup stages a (H + 4k) x (16 WO + 32) tile of the int8 lattice into LDS, de-interleaved into two
+//     colour planes of 0/1 "up" flags (8 same-colour sites of a row = one octet = one uint64),
+//   * runs 2k half-sweeps entirely in LDS (the region that is still exact shrinks by one site per half-sweep:
+//     2k halo rows, one halo octet = 16 columns >= 2k each side), and
+//   * writes the H x 16 WO interior to the OTHER lattice buffer (neighbouring tiles read this tile's pre-launch
+//     halo, so the launch is out of place; the host ping-pongs).
+// HBM traffic is 2/k bytes per spin update instead of 2; the kernel is VALU bound (Philox), so per octet:
+//   one Philox4x32-10 block -> 8 x 16 random bits; neighbour sums with packed byte adds; 16-bit thresholds
+//   picked per site with v_perm_b32 byte look-ups; v_pk_sub_i16 (saturating) compares two sites per
+//   instruction; only an exact tie of the top 16 bits (2^-16 per site) evaluates the low half.
+#include "ising2d.h"
 
-struct tsu_ising2d;
+typedef short v2s __attribute__((ext_vector_type(2)));
+typedef unsigned short v2us __attribute__((ext_vector_type(2)));
 
-int tsu_ising2d_tiled_supported(const tsu_ising2d*) { return 0; }
+struct TiledParams {
+    const int8_t* src;  // owned row 0 of the source buffer
+    int8_t* dst;        // owned row 0 of the destination buffer
+    long long pitch;
+    int rows, nchunks;           // owned rows; cols / 16
+    long long row0, total_rows;  // global row of owned row 0; global lattice height
+    int wrap_rows, ghost;        // source rows wrap inside the buffer, or come from `ghost` ghost rows
+    int k;                       // sweeps in this launch
+    int tiles_x;
+    uint32_t k0, k1, sweep0, tag_hi, tag_lo;
+    uint32_t tblH0, tblH1, tblL0, tblL1;  // (min(thr >> 16, 65535) ^ 0x8000) for up = 0..4, split into byte tables
+    uint64_t thr[5];                      // full thresholds (degree 4) for the tie path
+};
 
-int tsu_ising2d_tiled_sweep(tsu_ising2d*, int, uint64_t, uint32_t, uint32_t) { return TSU_E_UNSUPPORTED; }
+static __device__ __forceinline__ uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel) {
+    return __builtin_amdgcn_perm(s0, s1, sel);
+}
+static __device__ __forceinline__ uint32_t subsat16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(v2s, a), __builtin_bit_cast(v2s, b)));
+}
+static __device__ __forceinline__ uint32_t minu16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(v2us, a), __builtin_bit_cast(v2us, b)));
+}
+
+// exact resolution of the (rare) fields whose top 16 bits tie with the threshold: d fields that are 0.
+// Cold path (probability 2^-16 per site): kept out of line and register-to-register (no arrays by address).
+static __device__ __noinline__ u32x4 resolve_ties(u32x4 d, u32x4 w, uint32_t cnt_lo, uint32_t cnt_hi, const uint64_t* s_thr,
+                                                  uint32_t cq, uint32_t Rg, uint32_t hs, uint32_t tag_lo, uint32_t k0,
+                                                  uint32_t k1) {
+    const u32x4 l = tsu_philox(cq, Rg, hs, tag_lo, k0, k1);
+#define TSU_FIX(DW, WW, LW, CNT, B0)                                                                            \
+    _Pragma("unroll") for (int hlf = 0; hlf < 2; ++hlf) {                                                       \
+        const uint32_t sh = 16u * hlf;                                                                          \
+        if (((DW >> sh) & 0xFFFFu) == 0) {                                                                      \
+            const uint32_t c = (CNT >> (8 * (B0 + hlf))) & 0xFFu;                                               \
+            const uint64_t u = ((uint64_t)(((WW >> sh) & 0xFFFFu) ^ 0x8000u) << 16) | ((LW >> sh) & 0xFFFFu);   \
+            const uint32_t f = (u < s_thr[c]) ? 0x8000u : 0x0001u; /* negative field = accept */                \
+            DW = (DW & ~(0xFFFFu << sh)) | (f << sh);                                                           \
+        }                                                                                                       \
+    }
+    TSU_FIX(d.x, w.x, l.x, cnt_lo, 0)
+    TSU_FIX(d.y, w.y, l.y, cnt_lo, 2)
+    TSU_FIX(d.z, w.z, l.z, cnt_hi, 0)
+    TSU_FIX(d.w, w.w, l.w, cnt_hi, 2)
+#undef TSU_FIX
+    return d;
+}
+
+// One parity class of one half-sweep: rows trf, trf+2, ... (n_rows of them), all NO octets of each row.
+// PAR  = column parity of the updated colour in these rows (wave uniform -> compile-time shift pattern).
+// EDGE = the tile touches the lattice's wrap-around seam (global chunk / row indices need a modulo).
+struct RowsCtx {
+    const uint64_t* Ps;  // source plane (other colour)
+    uint64_t* Pd;        // destination plane (updated colour)
+    const uint64_t* s_thr;
+    int trf, n_rows;     // first tile row of the class, number of rows
+    int q0m1;            // global chunk index of tile octet 0 (may be -1 / beyond nchunks on EDGE tiles)
+    int rgf;             // global row of tile row trf, already wrapped
+    int nchunks, total_rows;
+    uint32_t hs, tag_hi, tag_lo, k0, k1;
+    uint32_t tblH0, tblH1, tblL0, tblL1;
+};
+
+template <int NO, int THREADS, int PAR, bool EDGE>
+static __device__ __forceinline__ void sweep_rows(const RowsCtx& c, int tid) {
+    constexpr int DA = THREADS / NO, DO = THREADS - DA * NO;
+    int a = tid / NO, oct = tid - a * NO;
+#pragma unroll 1
+    while (a < c.n_rows) {
+        const int idx = (c.trf + 2 * a) * NO + oct;
+        const uint64_t U = c.Ps[idx - NO], D = c.Ps[idx + NO], C = c.Ps[idx];
+        const uint32_t A = reinterpret_cast<const uint32_t*>(c.Ps)[2 * idx + (PAR ? 2 : -1)];
+        const uint32_t Clo = (uint32_t)C, Chi = (uint32_t)(C >> 32);
+        // the two horizontal neighbours of compact byte j are bytes j and j+1 (PAR) or j-1 and j (!PAR) of the other plane
+        const uint32_t Slo = PAR ? __builtin_amdgcn_alignbyte(Chi, Clo, 1) : __builtin_amdgcn_alignbyte(Clo, A, 3);
+        const uint32_t Shi = PAR ? __builtin_amdgcn_alignbyte(A, Chi, 1) : __builtin_amdgcn_alignbyte(Chi, Clo, 3);
+        const uint32_t cnt_lo = (uint32_t)U + (uint32_t)D + Clo + Slo;
+        const uint32_t cnt_hi = (uint32_t)(U >> 32) + (uint32_t)(D >> 32) + Chi + Shi;
+
+        int cq = c.q0m1 + oct, rg = c.rgf + 2 * a;
+        if (EDGE) {
+            if (cq < 0) cq += c.nchunks;
+            if (cq >= c.nchunks) cq -= c.nchunks;
+            if (rg >= c.total_rows) rg -= c.total_rows;
+        }
+        const u32x4 w = tsu_philox((uint32_t)cq, (uint32_t)rg, c.hs, c.tag_hi, c.k0, c.k1);
+
+        // per-site 16-bit thresholds: byte look-ups by the up-count, then interleave hi/lo bytes
+        const uint32_t Hl = perm(c.tblH1, c.tblH0, cnt_lo), Ll = perm(c.tblL1, c.tblL0, cnt_lo);
+        const uint32_t Hh = perm(c.tblH1, c.tblH0, cnt_hi), Lh = perm(c.tblL1, c.tblL0, cnt_hi);
+        u32x4 d;
+        d.x = subsat16(w.x, perm(Hl, Ll, 0x05010400u));
+        d.y = subsat16(w.y, perm(Hl, Ll, 0x07030602u));
+        d.z = subsat16(w.z, perm(Hh, Lh, 0x05010400u));
+        d.w = subsat16(w.w, perm(Hh, Lh, 0x07030602u));
+        const uint32_t mn = minu16(minu16(d.x, d.y), minu16(d.z, d.w));
+        if (__builtin_expect(((mn & 0xFFFFu) == 0) | ((mn >> 16) == 0), 0))
+            d = resolve_ties(d, w, cnt_lo, cnt_hi, c.s_thr, (uint32_t)cq, (uint32_t)rg, c.hs, c.tag_lo, c.k0, c.k1);
+        // sign bit of each 16-bit field = accept = new "up" flag
+        const uint32_t nlo = (perm(d.y, d.x, 0x07050301u) >> 7) & 0x01010101u;
+        const uint32_t nhi = (perm(d.w, d.z, 0x07050301u) >> 7) & 0x01010101u;
+        c.Pd[idx] = (uint64_t)nlo | ((uint64_t)nhi << 32);
+
+        a += DA;
+        oct += DO;
+        if (oct >= NO) {
+            oct -= NO;
+            ++a;
+        }
+    }
+}
+
+template <int H, int WO, int THREADS>
+__global__ __launch_bounds__(THREADS) void k1_tiled(TiledParams p) {
+    constexpr int NO = WO + 2;  // octets per tile row including one halo octet each side
+    extern __shared__ uint64_t lds[];
+    const int k = p.k;
+    const int TR = H + 4 * k;
+    uint64_t* plane0 = lds + 1;  // one guard octet in front (reads at octet -1 of row 0 stay in bounds)
+    uint64_t* plane1 = plane0 + TR * NO;
+    uint64_t* s_thr = plane1 + TR * NO + 1;
+    const int tid = threadIdx.x;
+    if (tid < 5) s_thr[tid] = p.thr[tid];
+
+    const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
+    const int q0 = tx * WO;      // first interior chunk (16 columns each)
+    const int r0 = ty * H;       // first interior owned row
+    const int Rb = r0 - 2 * k;   // owned-row index of tile row 0
+
+    // ---------------------------------------------------------------- stage the tile: HBM -> 2 colour planes
+    for (int idx = tid; idx < TR * NO; idx += THREADS) {
+        int tr = idx / NO, oct = idx - tr * NO;
+        int rl = Rb + tr;
+        int srow;
+        if (p.wrap_rows) {
+            srow = rl % p.rows;
+            if (srow < 0) srow += p.rows;
+        } else {
+            srow = rl < -p.ghost ? -p.ghost : (rl >= p.rows + p.ghost ? p.rows + p.ghost - 1 : rl);
+        }
+        int cq = q0 - 1 + oct;
+        if (cq < 0) cq += p.nchunks;
+        if (cq >= p.nchunks) cq -= p.nchunks;
+        if (cq >= p.nchunks) cq -= p.nchunks;
+        uint4 v = *reinterpret_cast<const uint4*>(p.src + (long long)srow * p.pitch + 16 * cq);
+        // +1 (0x01) -> 1, -1 (0xFF) -> 0
+        uint32_t f0 = ((v.x >> 1) & 0x01010101u) ^ 0x01010101u, f1 = ((v.y >> 1) & 0x01010101u) ^ 0x01010101u;
+        uint32_t f2 = ((v.z >> 1) & 0x01010101u) ^ 0x01010101u, f3 = ((v.w >> 1) & 0x01010101u) ^ 0x01010101u;
+        uint64_t ev = (uint64_t)perm(f1, f0, 0x06040200u) | ((uint64_t)perm(f3, f2, 0x06040200u) << 32);  // even columns
+        uint64_t od = (uint64_t)perm(f1, f0, 0x07050301u) | ((uint64_t)perm(f3, f2, 0x07050301u) << 32);  // odd columns
+        int gpar = (int)((p.row0 + rl) & 1);  // colour of the even columns of this row
+        (gpar ? plane1 : plane0)[idx] = ev;
+        (gpar ? plane0 : plane1)[idx] = od;
+    }
+
+    // global row of tile row 0, wrapped into [0, total_rows)
+    long long rg0 = (p.row0 + Rb) % p.total_rows;
+    if (rg0 < 0) rg0 += p.total_rows;
+
+    // tiles whose halo crosses the lattice's wrap-around seam need a modulo on the global indices
+    const bool edge = (q0 == 0) || (q0 + WO + 1 > p.nchunks) || (rg0 + TR > p.total_rows);
+    RowsCtx c;
+    c.s_thr = s_thr;
+    c.q0m1 = q0 - 1;
+    c.nchunks = p.nchunks;
+    c.total_rows = (int)p.total_rows;
+    c.tag_hi = p.tag_hi; c.tag_lo = p.tag_lo; c.k0 = p.k0; c.k1 = p.k1;
+    c.tblH0 = p.tblH0; c.tblH1 = p.tblH1; c.tblL0 = p.tblL0; c.tblL1 = p.tblL1;
+
+    // ---------------------------------------------------------------- 2k half-sweeps in LDS
+    for (int hsi = 0; hsi < 2 * k; ++hsi) {
+        __syncthreads();
+        const int kappa = hsi & 1;
+        c.hs = 2u * (p.sweep0 + (uint32_t)(hsi >> 1)) + (uint32_t)kappa;
+        c.Pd = kappa ? plane1 : plane0;
+        c.Ps = kappa ? plane0 : plane1;
+        const int tr_lo = 1 + hsi, tr_hi = TR - 2 - hsi;  // rows that are still exact after this half-sweep
+#pragma unroll 1
+        for (int pc = 0; pc < 2; ++pc) {
+            c.trf = tr_lo + ((tr_lo ^ pc) & 1);  // first row of this parity class
+            if (c.trf > tr_hi) continue;
+            c.n_rows = (tr_hi - c.trf) / 2 + 1;
+            int rgf = (int)rg0 + c.trf;
+            if (rgf >= c.total_rows) rgf -= c.total_rows;
+            c.rgf = rgf;
+            // column parity of colour kappa in these rows (block uniform)
+            const int par = (int)((p.row0 + Rb + c.trf + kappa) & 1);
+            if (edge) {
+                if (par) sweep_rows<NO, THREADS, 1, true>(c, tid);
+                else sweep_rows<NO, THREADS, 0, true>(c, tid);
+            } else {
+                if (par) sweep_rows<NO, THREADS, 1, false>(c, tid);
+                else sweep_rows<NO, THREADS, 0, false>(c, tid);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- interior -> HBM (other buffer)
+    for (int idx = tid; idx < H * WO; idx += THREADS) {
+        int hr = idx / WO, oc = idx - hr * WO + 1;
+        int rl = r0 + hr, cq = q0 + oc - 1;
+        if (rl >= p.rows || cq >= p.nchunks) continue;
+        int li = (2 * k + hr) * NO + oc;
+        int gpar = (int)((p.row0 + rl) & 1);
+        uint64_t ev = (gpar ? plane1 : plane0)[li], od = (gpar ? plane0 : plane1)[li];
+        // up flag -> spin byte: 1 -> 0x01, 0 -> 0xFF
+        uint32_t e0 = perm(0u, 0x000001FFu, (uint32_t)ev), e1 = perm(0u, 0x000001FFu, (uint32_t)(ev >> 32));
+        uint32_t o0 = perm(0u, 0x000001FFu, (uint32_t)od), o1 = perm(0u, 0x000001FFu, (uint32_t)(od >> 32));
+        uint4 v = make_uint4(perm(o0, e0, 0x05010400u), perm(o0, e0, 0x07030602u), perm(o1, e1, 0x05010400u),
+                             perm(o1, e1, 0x07030602u));
+        *reinterpret_cast<uint4*>(p.dst + (long long)rl * p.pitch + 16 * cq) = v;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+namespace {
+constexpr int TILE_H = 64, TILE_WO = 32, TILE_THREADS = 256, TILE_NO = TILE_WO + 2;
+constexpr int KMAX = 8;  // one halo octet (16 columns) covers 2k <= 16 half-sweeps
+}  // namespace
+
+int tsu_ising2d_tiled_supported(const tsu_ising2d* L) {
+    if (!L->periodic) return 0;                       // open edges: generic kernel
+    if (L->cols % 16 != 0) return 0;                  // octets must align with 16-byte chunks
+    if (L->cols / 16 < TILE_NO) return 0;             // tile wider than the lattice: generic kernel
+    if (!L->wrap_rows && L->ghost < 2) return 0;
+    if (L->total_rows < TILE_H + 4 * KMAX) return 0;  // single wrap of the global row index
+    return 1;
+}
+
+int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_t sweep0, uint32_t replica) {
+    tsu_ctx* ctx = L->ctx;
+    if (!L->alloc[1]) {
+        size_t bytes = (size_t)(L->rows + 2 * L->ghost) * L->pitch;
+        TSU_HIP_TRY(ctx, hipMalloc(&L->alloc[1], bytes));
+        TSU_HIP_TRY(ctx, hipMemsetAsync(L->alloc[1], 0, bytes, ctx->stream));
+    }
+    int kmax = L->sweeps_per_launch > 0 ? L->sweeps_per_launch : 4;
+    if (kmax > KMAX) kmax = KMAX;
+    if (!L->wrap_rows) {
+        // ghost rows are only fresh for the first launch: all requested sweeps go into one launch
+        TSU_REQUIRE(ctx, n_sweeps <= KMAX && 2 * n_sweeps <= L->ghost,
+                    "ising2d_sweep (tiled, slab): %d sweeps per ghost refresh exceed min(%d, ghost/2 = %d)", n_sweeps, KMAX,
+                    L->ghost / 2);
+        kmax = n_sweeps;
+    }
+    TiledParams p;
+    p.pitch = (long long)L->pitch;
+    p.rows = L->rows;
+    p.nchunks = L->cols / 16;
+    p.row0 = L->row0;
+    p.total_rows = L->total_rows;
+    p.wrap_rows = L->wrap_rows;
+    p.ghost = L->ghost;
+    p.tiles_x = (p.nchunks + TILE_WO - 1) / TILE_WO;
+    int tiles_y = (L->rows + TILE_H - 1) / TILE_H;
+    p.k0 = (uint32_t)seed;
+    p.k1 = (uint32_t)(seed >> 32);
+    p.tag_hi = TSU_TAG_ISING_HI | (replica << 8);
+    p.tag_lo = TSU_TAG_ISING_LO | (replica << 8);
+    uint32_t t16[5];
+    for (int c = 0; c < 5; ++c) {
+        uint64_t thr = L->table[4 * 5 + c];
+        p.thr[c] = thr;
+        uint32_t thi = (uint32_t)(thr >> 16);
+        if (thi > 65535u) thi = 65535u;
+        t16[c] = thi ^ 0x8000u;
+    }
+    p.tblL0 = (t16[0] & 0xFF) | ((t16[1] & 0xFF) << 8) | ((t16[2] & 0xFF) << 16) | ((t16[3] & 0xFF) << 24);
+    p.tblL1 = (t16[4] & 0xFF);
+    p.tblH0 = (t16[0] >> 8) | ((t16[1] >> 8) << 8) | ((t16[2] >> 8) << 16) | ((t16[3] >> 8) << 24);
+    p.tblH1 = (t16[4] >> 8);
+    static bool attr_set = false;
+    if (!attr_set) {
+        TSU_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k1_tiled<TILE_H, TILE_WO, TILE_THREADS>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    for (int done = 0; done < n_sweeps;) {
+        int k = n_sweeps - done < kmax ? n_sweeps - done : kmax;
+        p.k = k;
+        p.sweep0 = sweep0 + (uint32_t)done;
+        p.src = L->alloc[L->cur] + (size_t)L->ghost * L->pitch;
+        p.dst = L->alloc[L->cur ^ 1] + (size_t)L->ghost * L->pitch;
+        int TR = TILE_H + 4 * k;
+        size_t lds_bytes = ((size_t)2 * TR * TILE_NO + 2 + 5) * sizeof(uint64_t);
+        k1_tiled<TILE_H, TILE_WO, TILE_THREADS><<<(unsigned)(p.tiles_x * tiles_y), TILE_THREADS, lds_bytes, ctx->stream>>>(p);
+        L->cur ^= 1;
+        done += k;
+    }
+    TSU_HIP_TRY(ctx, hipGetLastError());
+    return TSU_OK;
+}
