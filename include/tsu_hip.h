@@ -109,6 +109,16 @@ int tsu_ising2d_set_kernel(tsu_ising2d* lat, int kernel, int sweeps_per_launch);
  * For a slab: ghost rows must be fresh on entry and n_sweeps <= ghost/2. */
 int tsu_ising2d_sweep(tsu_ising2d* lat, int n_sweeps, uint64_t seed, uint32_t sweep0, uint32_t replica);
 
+/* Split form of tsu_ising2d_sweep for slabs, so the host can overlap the halo exchange with compute:
+ * TSU_PART_INTERIOR updates the tile rows that do not read ghost rows (may run while ghosts are in flight and
+ * does not publish anything); TSU_PART_BOUNDARY updates the remaining tile rows and publishes the new state
+ * (after it, tsu_ising2d_row_ptr / get_spins see the swept lattice).  Call INTERIOR then BOUNDARY with the same
+ * arguments; TSU_PART_ALL is tsu_ising2d_sweep.  TSU_E_UNSUPPORTED when the lattice is not on the tiled kernel. */
+#define TSU_PART_ALL 0
+#define TSU_PART_INTERIOR 1
+#define TSU_PART_BOUNDARY 2
+int tsu_ising2d_sweep_part(tsu_ising2d* lat, int n_sweeps, uint64_t seed, uint32_t sweep0, uint32_t replica, int part);
+
 /* sum_s = sum of spins, sum_bonds = sum over nearest-neighbour bonds of s_i*s_j (owned rows; the bond to
  * the row below the slab is included when that row exists).  M = sum_s/N, E = -J*sum_bonds - h*sum_s. */
 int tsu_ising2d_observables(tsu_ising2d* lat, int64_t* sum_s, int64_t* sum_bonds);

@@ -335,3 +335,13 @@ def ising2d_site_uniforms(rows, cols, hs, seed, replica=0):
     lib().ora_ising2d_site_uniforms(_p(out, C.c_uint32), C.c_int(rows), C.c_int(cols), C.c_uint32(hs),
                                     C.c_uint64(seed), C.c_uint32(replica))
     return out
+
+
+def ising2d_sweep_window(block, row_global0, total_rows, periodic, table, n_sweeps, seed, sweep0=0, replica=0):
+    """Sweeps on a window of rows of a larger lattice (see ora_ising2d_sweep_window); returns a new array."""
+    s = np.ascontiguousarray(block, dtype=np.int8).copy()
+    t = np.ascontiguousarray(table, dtype=np.uint64)
+    lib().ora_ising2d_sweep_window(_p(s, C.c_int8), C.c_int(s.shape[0]), C.c_int(s.shape[1]), C.c_int64(row_global0),
+                                   C.c_int64(total_rows), C.c_int(int(bool(periodic))), _p(t, C.c_uint64), C.c_int(n_sweeps),
+                                   C.c_uint64(seed), C.c_uint32(sweep0), C.c_uint32(replica))
+    return s

@@ -336,3 +336,41 @@ void ora_ising2d_site_uniforms(uint32_t *out, int rows, int cols, uint32_t hs, u
     for (int r = 0; r < rows; ++r)
         for (int c = 0; c < cols; ++c) out[(size_t)r * cols + c] = site_uniform((uint32_t)r, c, hs, seed, replica);
 }
+
+/*
+ * Window form of ora_ising2d_sweep, for slab-decomposition tests: `spins` holds block_rows consecutive rows of a
+ * total_rows x cols lattice starting at global row `row_global0` (taken modulo total_rows when periodic).  Rows
+ * outside the window are unknown and treated as absent, so after h half-sweeps only window rows [h, block_rows-h)
+ * are exact -- unless the window edge is the lattice's own open edge, or the window is the whole periodic lattice
+ * (then rows wrap inside it).  RNG counters and colours use GLOBAL coordinates, which is what makes any row
+ * decomposition reproduce the single-lattice trajectory bit for bit.
+ */
+void ora_ising2d_sweep_window(int8_t *spins, int block_rows, int cols, int64_t row_global0, int64_t total_rows,
+                              int periodic, const uint64_t table[25], int n_sweeps, uint64_t seed, uint32_t sweep0,
+                              uint32_t replica) {
+    const int whole = (block_rows == total_rows);
+    for (int s = 0; s < n_sweeps; ++s) {
+        uint32_t t = sweep0 + (uint32_t)s;
+        for (int colour = 0; colour < 2; ++colour) {
+            uint32_t hs = 2u * t + (uint32_t)colour;
+            for (int r = 0; r < block_rows; ++r) {
+                int64_t R = row_global0 + r;
+                if (periodic) { R %= total_rows; if (R < 0) R += total_rows; }
+                if (R < 0 || R >= total_rows) continue; /* window row outside an open lattice */
+                for (int c = (int)((R + colour) & 1); c < cols; c += 2) {
+                    int up = 0, deg = 0, rr, cc;
+                    rr = r - 1; if (rr < 0 && periodic && whole) rr = block_rows - 1;
+                    if (rr >= 0 && (periodic || R - 1 >= 0)) { deg++; up += spins[(size_t)rr * cols + c] > 0; }
+                    rr = r + 1; if (rr >= block_rows && periodic && whole) rr = 0;
+                    if (rr < block_rows && (periodic || R + 1 < total_rows)) { deg++; up += spins[(size_t)rr * cols + c] > 0; }
+                    cc = c - 1; if (cc < 0 && periodic) cc = cols - 1;
+                    if (cc >= 0) { deg++; up += spins[(size_t)r * cols + cc] > 0; }
+                    cc = c + 1; if (cc >= cols && periodic) cc = 0;
+                    if (cc < cols) { deg++; up += spins[(size_t)r * cols + cc] > 0; }
+                    uint32_t u = site_uniform((uint32_t)R, c, hs, seed, replica);
+                    spins[(size_t)r * cols + c] = ((uint64_t)u < table[deg * 5 + up]) ? 1 : -1;
+                }
+            }
+        }
+    }
+}

@@ -451,8 +451,13 @@ int tsu_ising2d_set_kernel(tsu_ising2d* L, int kernel, int sweeps_per_launch) {
 }
 
 int tsu_ising2d_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_t sweep0, uint32_t replica) {
+    return tsu_ising2d_sweep_part(L, n_sweeps, seed, sweep0, replica, TSU_PART_ALL);
+}
+
+int tsu_ising2d_sweep_part(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_t sweep0, uint32_t replica, int part) {
     if (!L) return TSU_E_INVALID;
     tsu_ctx* ctx = L->ctx;
+    TSU_REQUIRE(ctx, part >= TSU_PART_ALL && part <= TSU_PART_BOUNDARY, "ising2d_sweep_part: bad part %d", part);
     TSU_REQUIRE(ctx, n_sweeps >= 0, "ising2d_sweep: n_sweeps must be >= 0");
     TSU_REQUIRE(ctx, L->have_table, "ising2d_sweep: call tsu_ising2d_set_model / set_thresholds first");
     TSU_REQUIRE(ctx, (uint64_t)sweep0 + (uint64_t)n_sweeps <= (1ull << 31), "ising2d_sweep: sweep counter overflow");
@@ -461,8 +466,10 @@ int tsu_ising2d_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_t swee
     if (n_sweeps == 0) return TSU_OK;
     TSU_HIP_TRY(ctx, hipEventRecord(L->ev0, ctx->stream));
     int use_tiled = (L->kernel == TSU_KERNEL_TILED) || (L->kernel == TSU_KERNEL_AUTO && tsu_ising2d_tiled_supported(L));
+    if (part != TSU_PART_ALL && !(use_tiled && tsu_ising2d_tiled_part_supported(L)))
+        return tsu_fail(ctx, TSU_E_UNSUPPORTED, "ising2d_sweep_part: split sweeps need a slab on the tiled kernel with rows %% 64 == 0");
     if (use_tiled) {
-        int rc = tsu_ising2d_tiled_sweep(L, n_sweeps, seed, sweep0, replica);
+        int rc = tsu_ising2d_tiled_sweep(L, n_sweeps, seed, sweep0, replica, part);
         if (rc != TSU_OK) return rc;
     } else {
         K1Params p = make_params(L, L->alloc[L->cur]);

@@ -26,6 +26,7 @@ struct TiledParams {
     int wrap_rows, ghost;        // source rows wrap inside the buffer, or come from `ghost` ghost rows
     int k;                       // sweeps in this launch
     int tiles_x;
+    int ty_first, ty_stride;     // tile row of block b: ty_first + (b / tiles_x) * ty_stride
     uint32_t k0, k1, sweep0, tag_hi, tag_lo;
     uint32_t tblH0, tblH1, tblL0, tblL1;  // (min(thr >> 16, 65535) ^ 0x8000) for up = 0..4, split into byte tables
     uint64_t thr[5];                      // full thresholds (degree 4) for the tie path
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(THREADS) void k1_tiled(TiledParams p) {
     const int tid = threadIdx.x;
     if (tid < 5) s_thr[tid] = p.thr[tid];
 
-    const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
+    const int tx = blockIdx.x % p.tiles_x, ty = p.ty_first + (blockIdx.x / p.tiles_x) * p.ty_stride;
     const int q0 = tx * WO;      // first interior chunk (16 columns each)
     const int r0 = ty * H;       // first interior owned row
     const int Rb = r0 - 2 * k;   // owned-row index of tile row 0
@@ -247,7 +248,12 @@ int tsu_ising2d_tiled_supported(const tsu_ising2d* L) {
     return 1;
 }
 
-int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_t sweep0, uint32_t replica) {
+// split (interior / boundary) launches: ghost-row slabs whose tile rows are all full
+int tsu_ising2d_tiled_part_supported(const tsu_ising2d* L) {
+    return tsu_ising2d_tiled_supported(L) && !L->wrap_rows && (L->rows % TILE_H) == 0;
+}
+
+int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_t sweep0, uint32_t replica, int part) {
     tsu_ctx* ctx = L->ctx;
     if (!L->alloc[1]) {
         size_t bytes = (size_t)(L->rows + 2 * L->ghost) * L->pitch;
@@ -303,8 +309,20 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
         p.dst = L->alloc[L->cur ^ 1] + (size_t)L->ghost * L->pitch;
         int TR = TILE_H + 4 * k;
         size_t lds_bytes = ((size_t)2 * TR * TILE_NO + 2 + 5) * sizeof(uint64_t);
-        k1_tiled<TILE_H, TILE_WO, TILE_THREADS><<<(unsigned)(p.tiles_x * tiles_y), TILE_THREADS, lds_bytes, ctx->stream>>>(p);
-        L->cur ^= 1;
+        // tile rows 0 and tiles_y-1 read ghost rows (2k <= H); the others only read owned rows
+        int n_ty = tiles_y;
+        p.ty_first = 0;
+        p.ty_stride = 1;
+        if (part == TSU_PART_INTERIOR) {
+            p.ty_first = 1;
+            n_ty = tiles_y - 2;
+        } else if (part == TSU_PART_BOUNDARY && tiles_y >= 2) {
+            p.ty_stride = tiles_y - 1;
+            n_ty = 2;
+        }
+        if (n_ty > 0)
+            k1_tiled<TILE_H, TILE_WO, TILE_THREADS><<<(unsigned)(p.tiles_x * n_ty), TILE_THREADS, lds_bytes, ctx->stream>>>(p);
+        if (part != TSU_PART_INTERIOR) L->cur ^= 1;  // INTERIOR does not publish; BOUNDARY (or ALL) does
         done += k;
     }
     TSU_HIP_TRY(ctx, hipGetLastError());

@@ -16,6 +16,7 @@ TSU_E_INVALID, TSU_E_NOMEM, TSU_E_HIP, TSU_E_RCCL, TSU_E_UNSUPPORTED = -1, -2, -
 MODE_PHYSICAL, MODE_COMPAT = 0, 1
 DTYPE_F64, DTYPE_F32 = 0, 1
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_TILED = 0, 1, 2
+PART_ALL, PART_INTERIOR, PART_BOUNDARY = 0, 1, 2
 
 
 class HipUnavailableError(RuntimeError):
@@ -60,6 +61,7 @@ SIGNATURES = {
     "tsu_ising2d_set_model": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double, C.c_int]),
     "tsu_ising2d_set_kernel": (C.c_int, [_vp, C.c_int, C.c_int]),
     "tsu_ising2d_sweep": (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32]),
+    "tsu_ising2d_sweep_part": (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]),
     "tsu_ising2d_observables": (C.c_int, [_vp, _i64p, _i64p]),
     "tsu_ising2d_row_ptr": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "tsu_ising2d_last_sweep_ms": (C.c_int, [_vp, _f32p]),
@@ -239,6 +241,9 @@ class Lattice:
 
     def sweep(self, n_sweeps, seed, sweep0=0, replica=0):
         self.ctx.check(self.lib.tsu_ising2d_sweep(self.h, int(n_sweeps), int(seed), int(sweep0), int(replica)))
+
+    def sweep_part(self, n_sweeps, seed, sweep0, part, replica=0):
+        self.ctx.check(self.lib.tsu_ising2d_sweep_part(self.h, int(n_sweeps), int(seed), int(sweep0), int(replica), int(part)))
 
     def observables(self):
         a, b = C.c_int64(0), C.c_int64(0)

@@ -1,0 +1,224 @@
+"""Row-slab domain decomposition of the 2-D lattice across the GPUs of one node (one process per GPU).
+
+The reference has no parallelism of any kind; this is new design for the path
+``IsingGrid`` / ``IsingModel2D.gibbs_update`` at sizes one GPU cannot hold or should not sweep alone.
+
+Rank r owns rows [r*R, (r+1)*R) of a (P*R) x cols lattice plus ``ghost = 2k`` ghost rows on each side.  Every k
+sweeps the ranks exchange their 2k boundary rows with the rank above and below (``torch.distributed``
+point-to-point, i.e. RCCL send/recv over xGMI with the ``nccl`` backend): one exchange per k sweeps instead of
+two per sweep, because each half-sweep consumes one ghost row.  Philox counters use
+GLOBAL (row, column, sweep) coordinates, so the trajectory is bit-identical for every P (tested).
+
+Overlap: the tile rows that do not touch ghost rows (all but the first and last 64 rows of the slab) are swept
+on the compute stream while the ghost rows travel on a second stream; the two boundary tile rows follow once the
+exchange has landed (``tsu_ising2d_sweep_part``).  There is no collective on the sweep path; observables need
+one all-reduce of two int64.
+"""
+from typing import Optional
+
+import numpy as np
+
+from . import _hip
+
+
+class _DeviceRows:
+    """Zero-copy view of lattice rows in libtsu_hip's device memory for torch (``__cuda_array_interface__``)."""
+
+    def __init__(self, ptr: int, n_rows: int, pitch: int):
+        self.__cuda_array_interface__ = {"shape": (n_rows, pitch), "typestr": "|i1", "data": (int(ptr), False),
+                                         "version": 3, "strides": None}
+
+
+class SlabLattice:
+    """A (world_size * rows_per_rank) x cols periodic or open lattice, one row slab per rank.
+
+    ``engine`` is the per-slab lattice class (default: the HIP lattice :class:`tsu._hip.Lattice`; the CPU-only
+    tests inject a test double, the product never does).  ``group``/``backend`` come from ``torch.distributed``;
+    with ``world_size == 1`` no process group is needed and the exchange is a device-to-device copy.
+    """
+
+    def __init__(self, rows_per_rank: int, cols: int, periodic: bool = True, sweeps_per_exchange: int = 4,
+                 seed: int = 0, group=None, engine=None, overlap: bool = True, device: Optional[int] = None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.group = group
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if self.distributed else 0
+        self.world = dist.get_world_size(group) if self.distributed else 1
+        self.backend = dist.get_backend(group) if self.distributed else "none"
+        self.rows, self.cols, self.periodic = int(rows_per_rank), int(cols), bool(periodic)
+        self.total_rows = self.rows * self.world
+        self.k = int(sweeps_per_exchange)
+        self.ghost = 2 * self.k
+        if self.ghost > self.rows:
+            raise ValueError(f"sweeps_per_exchange={self.k} needs {self.ghost} ghost rows but the slab has {self.rows}")
+        self.seed = int(seed)
+        self.sweep_count = 0
+        self.up = (self.rank - 1) % self.world if (self.periodic or self.rank > 0) else None
+        self.down = (self.rank + 1) % self.world if (self.periodic or self.rank < self.world - 1) else None
+        self._host_staged = engine is not None or self.backend == "gloo"  # ghosts staged through host memory
+        if engine is None:
+            ctx = _hip.Context.default() if device is None else _hip.Context(device)
+            self.ctx = ctx
+            self.lat = _hip.Lattice(self.rows, self.cols, self.periodic, ctx=ctx, total_rows=self.total_rows,
+                                    row0=self.rank * self.rows, ghost=self.ghost)
+            self.device_index = torch.cuda.current_device() if device is None else device
+            # the library enqueues on torch's current stream so that RCCL ops and kernels are ordered by torch
+            self.compute_stream = torch.cuda.current_stream(self.device_index)
+            ctx.set_stream(self.compute_stream.cuda_stream)
+            self.comm_stream = torch.cuda.Stream(self.device_index) if (overlap and self.world > 1) else None
+        else:
+            self.ctx = None
+            self.lat = engine(self.rows, self.cols, self.periodic, total_rows=self.total_rows, row0=self.rank * self.rows,
+                              ghost=self.ghost)
+            self.comm_stream = None
+        # split (interior / boundary) launches need the tiled kernel and full tile rows: decided at the first sweep
+        self._split = None if (engine is None and self.comm_stream is not None and not self._host_staged) else False
+        self._views = {}
+
+    # ------------------------------------------------------------------ state
+    def randomize(self, seed: Optional[int] = None):
+        self.lat.randomize(self.seed if seed is None else int(seed))
+
+    def set_model(self, J: float, h: float, T: float, mode: int = _hip.MODE_PHYSICAL):
+        self.lat.set_model(J, h, T, mode)
+
+    def set_thresholds(self, table):
+        self.lat.set_thresholds(table)
+
+    def set_local_spins(self, spins):
+        self.lat.set_spins(spins)
+
+    def local_spins(self) -> np.ndarray:
+        return self.lat.get_spins()
+
+    # ------------------------------------------------------------------ halo exchange
+    def _rows_tensor(self, local_row: int, n_rows: int):
+        ptr, pitch = self.lat.row_ptr(local_row)
+        key = (ptr, n_rows)
+        t = self._views.get(key)
+        if t is None:
+            t = self.torch.as_tensor(_DeviceRows(ptr, n_rows, pitch), device=f"cuda:{self.device_index}")
+            self._views[key] = t
+        return t
+
+    def _exchange_device(self):
+        """Ghost refresh with device buffers (RCCL send/recv, or a local copy when this rank is its own neighbour)."""
+        G, R = self.ghost, self.rows
+        top, bot = self._rows_tensor(0, G), self._rows_tensor(R - G, G)
+        gtop, gbot = self._rows_tensor(-G, G), self._rows_tensor(R, G)
+        if self.world == 1:
+            if self.periodic:
+                gtop.copy_(bot)
+                gbot.copy_(top)
+            return
+        dist = self.dist
+        ops = []
+        # order matters when up == down (two ranks): my first send (to up) pairs with the peer's first recv (from down)
+        if self.up is not None:
+            ops.append(dist.P2POp(dist.isend, top, self.up, self.group))
+        if self.down is not None:
+            ops.append(dist.P2POp(dist.isend, bot, self.down, self.group))
+        if self.down is not None:
+            ops.append(dist.P2POp(dist.irecv, gbot, self.down, self.group))
+        if self.up is not None:
+            ops.append(dist.P2POp(dist.irecv, gtop, self.up, self.group))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+    def _exchange_host(self):
+        """Ghost refresh staged through host memory (gloo backend / test doubles)."""
+        G, R = self.ghost, self.rows
+        torch, dist = self.torch, self.dist
+        top = torch.from_numpy(np.ascontiguousarray(self.lat.get_spins(0, G)))
+        bot = torch.from_numpy(np.ascontiguousarray(self.lat.get_spins(R - G, G)))
+        if self.world == 1:
+            if self.periodic:
+                self.lat.set_spins(bot.numpy(), row_first=-G)
+                self.lat.set_spins(top.numpy(), row_first=R)
+            return
+        gtop, gbot = torch.empty_like(top), torch.empty_like(bot)
+        ops = []
+        if self.up is not None:
+            ops.append(dist.P2POp(dist.isend, top, self.up, self.group))
+        if self.down is not None:
+            ops.append(dist.P2POp(dist.isend, bot, self.down, self.group))
+        if self.down is not None:
+            ops.append(dist.P2POp(dist.irecv, gbot, self.down, self.group))
+        if self.up is not None:
+            ops.append(dist.P2POp(dist.irecv, gtop, self.up, self.group))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        if self.up is not None:
+            self.lat.set_spins(gtop.numpy(), row_first=-G)
+        if self.down is not None:
+            self.lat.set_spins(gbot.numpy(), row_first=R)
+
+    def exchange(self):
+        if self._host_staged:
+            self._exchange_host()
+        else:
+            self._exchange_device()
+
+    # ------------------------------------------------------------------ sweeps
+    def sweep(self, n_sweeps: int):
+        """n_sweeps checkerboard sweeps of the whole distributed lattice (asynchronous on the GPU path)."""
+        done = 0
+        while done < n_sweeps:
+            k = min(self.k, n_sweeps - done)
+            if self._split is not False:
+                torch = self.torch
+                # boundary rows of the current state are final (previous BOUNDARY launch): start the exchange on
+                # the comm stream, sweep the interior tile rows meanwhile, then the two boundary tile rows
+                ready = torch.cuda.Event()
+                ready.record(self.compute_stream)
+                try:
+                    self.lat.sweep_part(k, self.seed, self.sweep_count, _hip.PART_INTERIOR)
+                    self._split = True
+                except _hip.UnsupportedError:
+                    if self._split is True:
+                        raise
+                    self._split = False
+                    continue
+                with torch.cuda.stream(self.comm_stream):
+                    self.comm_stream.wait_event(ready)
+                    self._exchange_device()
+                    landed = torch.cuda.Event()
+                    landed.record(self.comm_stream)
+                self.compute_stream.wait_event(landed)
+                self.lat.sweep_part(k, self.seed, self.sweep_count, _hip.PART_BOUNDARY)
+            else:
+                self.exchange()
+                self.lat.sweep(k, self.seed, self.sweep_count)
+            self.sweep_count += k
+            done += k
+
+    def observables(self):
+        """(sum of spins, sum over bonds) of the WHOLE lattice: local reductions + one all-reduce of two int64."""
+        self.exchange()  # the bond to the row below the slab needs a fresh ghost row
+        s, b = self.lat.observables()
+        if self.world == 1:
+            return s, b
+        t = self.torch.tensor([s, b], dtype=self.torch.int64)
+        if self.backend == "nccl":
+            t = t.cuda(self.device_index)
+        self.dist.all_reduce(t, group=self.group)
+        return int(t[0]), int(t[1])
+
+    def gather_spins(self) -> Optional[np.ndarray]:
+        """The whole lattice on rank 0 (tests / small lattices only)."""
+        mine = self.torch.from_numpy(self.local_spins().copy())
+        if self.world == 1:
+            return mine.numpy()
+        if self.backend == "nccl":
+            mine = mine.cuda(self.device_index)
+        parts = [self.torch.empty_like(mine) for _ in range(self.world)] if self.rank == 0 else None
+        self.dist.gather(mine, parts, dst=0, group=self.group)
+        if self.rank != 0:
+            return None
+        return np.concatenate([p.cpu().numpy() for p in parts])
+
+    def synchronize(self):
+        if self.ctx is not None:
+            self.ctx.synchronize()
