@@ -27,6 +27,7 @@ struct TiledParams {
     int k;                       // sweeps in this launch
     int tiles_x;
     int ty_first, ty_stride;     // tile row of block b: ty_first + (b / tiles_x) * ty_stride
+    int debug;                   // development timing aid (TSU_K1_DEBUG): 1 = skip HBM loads, 2 = skip loads and stores
     uint32_t k0, k1, sweep0, tag_hi, tag_lo;
     uint32_t tblH0, tblH1, tblL0, tblL1;  // (min(thr >> 16, 65535) ^ 0x8000) for up = 0..4, split into byte tables
     uint64_t thr[5];                      // full thresholds (degree 4) for the tie path
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(THREADS) void k1_tiled(TiledParams p) {
     const int Rb = r0 - 2 * k;   // owned-row index of tile row 0
 
     // ---------------------------------------------------------------- stage the tile: HBM -> 2 colour planes
-    for (int idx = tid; idx < TR * NO; idx += THREADS) {
+    for (int idx = tid; idx < (p.debug ? 0 : TR * NO); idx += THREADS) {
         int tr = idx / NO, oct = idx - tr * NO;
         int rl = Rb + tr;
         int srow;
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(THREADS) void k1_tiled(TiledParams p) {
     __syncthreads();
 
     // ---------------------------------------------------------------- interior -> HBM (other buffer)
-    for (int idx = tid; idx < H * WO; idx += THREADS) {
+    for (int idx = tid; idx < (p.debug >= 2 ? 0 : H * WO); idx += THREADS) {
         int hr = idx / WO, oc = idx - hr * WO + 1;
         int rl = r0 + hr, cq = q0 + oc - 1;
         if (rl >= p.rows || cq >= p.nchunks) continue;
@@ -233,28 +234,272 @@ __global__ __launch_bounds__(THREADS) void k1_tiled(TiledParams p) {
     }
 }
 
+// ================================================================== v2 inner loop
+// Same tile, same LDS layout, same results; the half-sweep body is restructured for instruction count and ILP:
+//   * a thread owns ONE octet column for the whole kernel (global chunk index fixed, no div/mod in the loop) and
+//     walks down the rows in pairs (r, r+1): the two rows share two of their three neighbour-row reads, and their
+//     two Philox blocks are independent dependency chains that the scheduler interleaves;
+//   * the ten round keys live in VGPRs (a v_xor with an SGPR operand issues at half the rate of a VGPR-only one);
+//   * one tie test covers both rows.
+struct PhiloxKeys {
+    uint32_t a[10], b[10];
+};
+
+static __device__ __forceinline__ PhiloxKeys make_keys(uint32_t k0, uint32_t k1) {
+    PhiloxKeys K;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t x = k0 + (uint32_t)r * TSU_PHILOX_W0, y = k1 + (uint32_t)r * TSU_PHILOX_W1;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(x) : "s"(x));  // opaque: keep the keys in vector registers
+        asm volatile("v_mov_b32 %0, %1" : "=v"(y) : "s"(y));
+        K.a[r] = x;
+        K.b[r] = y;
+    }
+    return K;
+}
+
+static __device__ __forceinline__ u32x4 philox_vk(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, const PhiloxKeys& K) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)TSU_PHILOX_M0 * c0;
+        uint64_t p1 = (uint64_t)TSU_PHILOX_M1 * c2;
+        uint32_t n0 = ((uint32_t)(p1 >> 32) ^ c1) ^ K.a[r];
+        uint32_t n2 = ((uint32_t)(p0 >> 32) ^ c3) ^ K.b[r];
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+    }
+    return u32x4{c0, c1, c2, c3};
+}
+
+struct Rows2Ctx {
+    const uint64_t* Ps;
+    uint64_t* Pd;
+    const uint64_t* s_thr;
+    int tr_lo, npairs;   // first tile row of the half-sweep's range, number of row pairs
+    int rgf;             // global row of tile row tr_lo (wrapped)
+    int total_rows;
+    uint32_t hs, tag_hi, tag_lo, k0, k1;
+    uint32_t tblH0, tblH1, tblL0, tblL1;
+};
+
+// thresholds for the 8 sites of one octet given their up-counts, compared with one Philox block: d < 0 = accept
+static __device__ __forceinline__ u32x4 compare_octet(const u32x4& w, uint32_t cnt_lo, uint32_t cnt_hi, uint32_t tH0,
+                                                      uint32_t tH1, uint32_t tL0, uint32_t tL1) {
+    const uint32_t Hl = perm(tH1, tH0, cnt_lo), Ll = perm(tL1, tL0, cnt_lo);
+    const uint32_t Hh = perm(tH1, tH0, cnt_hi), Lh = perm(tL1, tL0, cnt_hi);
+    u32x4 d;
+    d.x = subsat16(w.x, perm(Hl, Ll, 0x05010400u));
+    d.y = subsat16(w.y, perm(Hl, Ll, 0x07030602u));
+    d.z = subsat16(w.z, perm(Hh, Lh, 0x05010400u));
+    d.w = subsat16(w.w, perm(Hh, Lh, 0x07030602u));
+    return d;
+}
+
+static __device__ __forceinline__ bool has_zero_field(const u32x4& d) {
+    const uint32_t mn = minu16(minu16(d.x, d.y), minu16(d.z, d.w));
+    return ((mn & 0xFFFFu) == 0) | ((mn >> 16) == 0);
+}
+
+static __device__ __forceinline__ uint64_t pack_flags(const u32x4& d) {
+    const uint32_t nlo = (perm(d.y, d.x, 0x07050301u) >> 7) & 0x01010101u;
+    const uint32_t nhi = (perm(d.w, d.z, 0x07050301u) >> 7) & 0x01010101u;
+    return (uint64_t)nlo | ((uint64_t)nhi << 32);
+}
+
+// P0 = column parity of the updated colour in row tr_lo (and 1-P0 in the row below it)
+template <int NO, int RL, int P0, bool EDGE>
+static __device__ __forceinline__ void sweep_pairs(const Rows2Ctx& c, const PhiloxKeys& K, int al, int oct, uint32_t cq) {
+    int idx = (c.tr_lo + 2 * al) * NO + oct;
+    int rg = c.rgf + 2 * al;
+#pragma unroll 1
+    for (int a = al; a < c.npairs; a += RL, idx += 2 * RL * NO, rg += 2 * RL) {
+        const uint64_t R0 = c.Ps[idx - NO], R1 = c.Ps[idx], R2 = c.Ps[idx + NO], R3 = c.Ps[idx + 2 * NO];
+        const uint32_t A0 = reinterpret_cast<const uint32_t*>(c.Ps)[2 * idx + (P0 ? 2 : -1)];
+        const uint32_t A1 = reinterpret_cast<const uint32_t*>(c.Ps)[2 * (idx + NO) + (P0 ? -1 : 2)];
+        const uint32_t C0l = (uint32_t)R1, C0h = (uint32_t)(R1 >> 32), C1l = (uint32_t)R2, C1h = (uint32_t)(R2 >> 32);
+        // horizontal neighbours: compact bytes (j, j+1) when the parity is 1, (j-1, j) when it is 0
+        const uint32_t S0l = P0 ? __builtin_amdgcn_alignbyte(C0h, C0l, 1) : __builtin_amdgcn_alignbyte(C0l, A0, 3);
+        const uint32_t S0h = P0 ? __builtin_amdgcn_alignbyte(A0, C0h, 1) : __builtin_amdgcn_alignbyte(C0h, C0l, 3);
+        const uint32_t S1l = P0 ? __builtin_amdgcn_alignbyte(C1l, A1, 3) : __builtin_amdgcn_alignbyte(C1h, C1l, 1);
+        const uint32_t S1h = P0 ? __builtin_amdgcn_alignbyte(C1h, C1l, 3) : __builtin_amdgcn_alignbyte(A1, C1h, 1);
+        // R1 + R2 is shared by both rows' vertical+centre sums
+        const uint32_t ml = C0l + C1l, mh = C0h + C1h;
+        const uint32_t cnt0l = (uint32_t)R0 + ml + S0l, cnt0h = (uint32_t)(R0 >> 32) + mh + S0h;
+        const uint32_t cnt1l = (uint32_t)R3 + ml + S1l, cnt1h = (uint32_t)(R3 >> 32) + mh + S1h;
+
+        int rga = rg, rgb = rg + 1;
+        if (EDGE) {
+            if (rga >= c.total_rows) rga -= c.total_rows;
+            if (rgb >= c.total_rows) rgb -= c.total_rows;
+        }
+        const u32x4 w0 = philox_vk(cq, (uint32_t)rga, c.hs, c.tag_hi, K);
+        const u32x4 w1 = philox_vk(cq, (uint32_t)rgb, c.hs, c.tag_hi, K);
+        u32x4 d0 = compare_octet(w0, cnt0l, cnt0h, c.tblH0, c.tblH1, c.tblL0, c.tblL1);
+        u32x4 d1 = compare_octet(w1, cnt1l, cnt1h, c.tblH0, c.tblH1, c.tblL0, c.tblL1);
+        const uint32_t mn = minu16(minu16(minu16(d0.x, d0.y), minu16(d0.z, d0.w)), minu16(minu16(d1.x, d1.y), minu16(d1.z, d1.w)));
+        if (__builtin_expect(((mn & 0xFFFFu) == 0) | ((mn >> 16) == 0), 0)) {
+            if (has_zero_field(d0)) d0 = resolve_ties(d0, w0, cnt0l, cnt0h, c.s_thr, cq, (uint32_t)rga, c.hs, c.tag_lo, c.k0, c.k1);
+            if (has_zero_field(d1)) d1 = resolve_ties(d1, w1, cnt1l, cnt1h, c.s_thr, cq, (uint32_t)rgb, c.hs, c.tag_lo, c.k0, c.k1);
+        }
+        c.Pd[idx] = pack_flags(d0);
+        c.Pd[idx + NO] = pack_flags(d1);
+    }
+}
+
+template <int H, int WO, int THREADS>
+__global__ __launch_bounds__(THREADS) void k1_tiled2(TiledParams p) {
+    constexpr int NO = WO + 2;
+    constexpr int RL = THREADS / NO;  // row lanes: threads [0, RL*NO) sweep, all threads load / store
+    extern __shared__ uint64_t lds[];
+    const int k = p.k;
+    const int TR = H + 4 * k;
+    uint64_t* plane0 = lds + 1;
+    uint64_t* plane1 = plane0 + TR * NO;
+    uint64_t* s_thr = plane1 + TR * NO + NO + 1;  // one spare row: the pair loop reads row idx + 2 NO of the last pair
+    const int tid = threadIdx.x;
+    if (tid < 5) s_thr[tid] = p.thr[tid];
+
+    const int tx = blockIdx.x % p.tiles_x, ty = p.ty_first + (blockIdx.x / p.tiles_x) * p.ty_stride;
+    const int q0 = tx * WO, r0 = ty * H, Rb = r0 - 2 * k;
+
+    for (int idx = tid; idx < (p.debug ? 0 : TR * NO); idx += THREADS) {
+        int tr = idx / NO, oct = idx - tr * NO;
+        int rl = Rb + tr;
+        int srow;
+        if (p.wrap_rows) {
+            srow = rl % p.rows;
+            if (srow < 0) srow += p.rows;
+        } else {
+            srow = rl < -p.ghost ? -p.ghost : (rl >= p.rows + p.ghost ? p.rows + p.ghost - 1 : rl);
+        }
+        int cq = q0 - 1 + oct;
+        if (cq < 0) cq += p.nchunks;
+        if (cq >= p.nchunks) cq -= p.nchunks;
+        if (cq >= p.nchunks) cq -= p.nchunks;
+        uint4 v = *reinterpret_cast<const uint4*>(p.src + (long long)srow * p.pitch + 16 * cq);
+        uint32_t f0 = ((v.x >> 1) & 0x01010101u) ^ 0x01010101u, f1 = ((v.y >> 1) & 0x01010101u) ^ 0x01010101u;
+        uint32_t f2 = ((v.z >> 1) & 0x01010101u) ^ 0x01010101u, f3 = ((v.w >> 1) & 0x01010101u) ^ 0x01010101u;
+        uint64_t ev = (uint64_t)perm(f1, f0, 0x06040200u) | ((uint64_t)perm(f3, f2, 0x06040200u) << 32);
+        uint64_t od = (uint64_t)perm(f1, f0, 0x07050301u) | ((uint64_t)perm(f3, f2, 0x07050301u) << 32);
+        int gpar = (int)((p.row0 + rl) & 1);
+        (gpar ? plane1 : plane0)[idx] = ev;
+        (gpar ? plane0 : plane1)[idx] = od;
+    }
+
+    long long rg0 = (p.row0 + Rb) % p.total_rows;
+    if (rg0 < 0) rg0 += p.total_rows;
+    const bool edge = (rg0 + TR > p.total_rows);
+    const int al = tid / NO, oct = tid - al * NO;
+    int cqi = q0 - 1 + oct;
+    if (cqi < 0) cqi += p.nchunks;
+    if (cqi >= p.nchunks) cqi -= p.nchunks;
+    if (cqi >= p.nchunks) cqi -= p.nchunks;
+    const uint32_t cq = (uint32_t)cqi;
+    const PhiloxKeys K = make_keys(p.k0, p.k1);
+
+    Rows2Ctx c;
+    c.s_thr = s_thr;
+    c.total_rows = (int)p.total_rows;
+    c.tag_hi = p.tag_hi; c.tag_lo = p.tag_lo; c.k0 = p.k0; c.k1 = p.k1;
+    c.tblH0 = p.tblH0; c.tblH1 = p.tblH1; c.tblL0 = p.tblL0; c.tblL1 = p.tblL1;
+
+    for (int hsi = 0; hsi < 2 * k; ++hsi) {
+        __syncthreads();
+        const int kappa = hsi & 1;
+        c.hs = 2u * (p.sweep0 + (uint32_t)(hsi >> 1)) + (uint32_t)kappa;
+        c.Pd = kappa ? plane1 : plane0;
+        c.Ps = kappa ? plane0 : plane1;
+        c.tr_lo = 1 + hsi;
+        c.npairs = (TR - 2 - 2 * hsi) / 2;  // rows [1 + hsi, TR - 2 - hsi] in pairs (TR is even)
+        int rgf = (int)rg0 + c.tr_lo;
+        if (rgf >= c.total_rows) rgf -= c.total_rows;
+        c.rgf = rgf;
+        const int par0 = (int)((p.row0 + Rb + c.tr_lo + kappa) & 1);
+        if (al < RL) {
+            if (edge) {
+                if (par0) sweep_pairs<NO, RL, 1, true>(c, K, al, oct, cq);
+                else sweep_pairs<NO, RL, 0, true>(c, K, al, oct, cq);
+            } else {
+                if (par0) sweep_pairs<NO, RL, 1, false>(c, K, al, oct, cq);
+                else sweep_pairs<NO, RL, 0, false>(c, K, al, oct, cq);
+            }
+        }
+    }
+    __syncthreads();
+
+    for (int idx = tid; idx < (p.debug >= 2 ? 0 : H * WO); idx += THREADS) {
+        int hr = idx / WO, oc = idx - hr * WO + 1;
+        int rl = r0 + hr, cqs = q0 + oc - 1;
+        if (rl >= p.rows || cqs >= p.nchunks) continue;
+        int li = (2 * k + hr) * NO + oc;
+        int gpar = (int)((p.row0 + rl) & 1);
+        uint64_t ev = (gpar ? plane1 : plane0)[li], od = (gpar ? plane0 : plane1)[li];
+        uint32_t e0 = perm(0u, 0x000001FFu, (uint32_t)ev), e1 = perm(0u, 0x000001FFu, (uint32_t)(ev >> 32));
+        uint32_t o0 = perm(0u, 0x000001FFu, (uint32_t)od), o1 = perm(0u, 0x000001FFu, (uint32_t)(od >> 32));
+        uint4 v = make_uint4(perm(o0, e0, 0x05010400u), perm(o0, e0, 0x07030602u), perm(o1, e1, 0x05010400u),
+                             perm(o1, e1, 0x07030602u));
+        *reinterpret_cast<uint4*>(p.dst + (long long)rl * p.pitch + 16 * cqs) = v;
+    }
+}
+
 // ------------------------------------------------------------------ host side
 namespace {
-constexpr int TILE_H = 64, TILE_WO = 32, TILE_THREADS = 256, TILE_NO = TILE_WO + 2;
 constexpr int KMAX = 8;  // one halo octet (16 columns) covers 2k <= 16 half-sweeps
+
+struct TileVariant {
+    int H, WO, threads;
+    void (*kernel)(TiledParams);
+};
+// tile shapes compiled in; TSU_TILE_VARIANT (env, development aid) or tsu_ising2d_set_kernel picks one
+const TileVariant kVariants[] = {
+    {64, 32, 256, k1_tiled<64, 32, 256>},
+    {64, 32, 512, k1_tiled<64, 32, 512>},
+    {128, 32, 512, k1_tiled<128, 32, 512>},
+    {64, 64, 512, k1_tiled<64, 64, 512>},
+    {32, 32, 256, k1_tiled<32, 32, 256>},
+    {128, 32, 1024, k1_tiled<128, 32, 1024>},
+    {64, 32, 512, k1_tiled2<64, 32, 512>},    // 6: v2 inner loop (row pairs, VGPR keys)
+    {64, 32, 256, k1_tiled2<64, 32, 256>},    // 7
+    {128, 32, 512, k1_tiled2<128, 32, 512>},  // 8
+    {128, 32, 1024, k1_tiled2<128, 32, 1024>},// 9
+    {64, 32, 1024, k1_tiled2<64, 32, 1024>},  // 10
+};
+constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+constexpr int kMaxH = 128, kMaxNO = 66;
+
+int pick_variant(const tsu_ising2d* L) {
+    static int env = -2;
+    if (env == -2) {
+        const char* e = getenv("TSU_TILE_VARIANT");
+        env = e ? atoi(e) : -1;
+    }
+    int v = env >= 0 && env < kNumVariants ? env : 1;
+    // a variant must fit the lattice (tile not wider than the lattice; single wrap of the global row index)
+    if (L->cols / 16 < kVariants[v].WO + 2 || L->total_rows < kVariants[v].H + 4 * KMAX) v = 0;
+    return v;
+}
 }  // namespace
 
 int tsu_ising2d_tiled_supported(const tsu_ising2d* L) {
-    if (!L->periodic) return 0;                       // open edges: generic kernel
-    if (L->cols % 16 != 0) return 0;                  // octets must align with 16-byte chunks
-    if (L->cols / 16 < TILE_NO) return 0;             // tile wider than the lattice: generic kernel
+    if (!L->periodic) return 0;                               // open edges: generic kernel
+    if (L->cols % 16 != 0) return 0;                          // octets must align with 16-byte chunks
+    if (L->cols / 16 < kVariants[0].WO + 2) return 0;         // tile wider than the lattice: generic kernel
     if (!L->wrap_rows && L->ghost < 2) return 0;
-    if (L->total_rows < TILE_H + 4 * KMAX) return 0;  // single wrap of the global row index
+    if (L->total_rows < kVariants[0].H + 4 * KMAX) return 0;  // single wrap of the global row index
     return 1;
 }
 
 // split (interior / boundary) launches: ghost-row slabs whose tile rows are all full
 int tsu_ising2d_tiled_part_supported(const tsu_ising2d* L) {
-    return tsu_ising2d_tiled_supported(L) && !L->wrap_rows && (L->rows % TILE_H) == 0;
+    return tsu_ising2d_tiled_supported(L) && !L->wrap_rows && (L->rows % kVariants[pick_variant(L)].H) == 0;
 }
 
 int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_t sweep0, uint32_t replica, int part) {
     tsu_ctx* ctx = L->ctx;
+    const TileVariant& tv = kVariants[pick_variant(L)];
+    const int TILE_H = tv.H, TILE_WO = tv.WO, TILE_NO = tv.WO + 2;
     if (!L->alloc[1]) {
         size_t bytes = (size_t)(L->rows + 2 * L->ghost) * L->pitch;
         TSU_HIP_TRY(ctx, hipMalloc(&L->alloc[1], bytes));
@@ -278,6 +523,14 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
     p.wrap_rows = L->wrap_rows;
     p.ghost = L->ghost;
     p.tiles_x = (p.nchunks + TILE_WO - 1) / TILE_WO;
+    {
+        static int dbg = -1;
+        if (dbg < 0) {
+            const char* e = getenv("TSU_K1_DEBUG");
+            dbg = e ? atoi(e) : 0;
+        }
+        p.debug = dbg;
+    }
     int tiles_y = (L->rows + TILE_H - 1) / TILE_H;
     p.k0 = (uint32_t)seed;
     p.k1 = (uint32_t)(seed >> 32);
@@ -295,11 +548,10 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
     p.tblL1 = (t16[4] & 0xFF);
     p.tblH0 = (t16[0] >> 8) | ((t16[1] >> 8) << 8) | ((t16[2] >> 8) << 16) | ((t16[3] >> 8) << 24);
     p.tblH1 = (t16[4] >> 8);
-    static bool attr_set = false;
-    if (!attr_set) {
-        TSU_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k1_tiled<TILE_H, TILE_WO, TILE_THREADS>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+    static bool attr_set[kNumVariants] = {};
+    if (!attr_set[&tv - kVariants]) {
+        TSU_HIP_TRY(ctx, hipFuncSetAttribute((const void*)tv.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[&tv - kVariants] = true;
     }
     for (int done = 0; done < n_sweeps;) {
         int k = n_sweeps - done < kmax ? n_sweeps - done : kmax;
@@ -308,7 +560,7 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
         p.src = L->alloc[L->cur] + (size_t)L->ghost * L->pitch;
         p.dst = L->alloc[L->cur ^ 1] + (size_t)L->ghost * L->pitch;
         int TR = TILE_H + 4 * k;
-        size_t lds_bytes = ((size_t)2 * TR * TILE_NO + 2 + 5) * sizeof(uint64_t);
+        size_t lds_bytes = ((size_t)2 * TR * TILE_NO + TILE_NO + 2 + 5) * sizeof(uint64_t);
         // tile rows 0 and tiles_y-1 read ghost rows (2k <= H); the others only read owned rows
         int n_ty = tiles_y;
         p.ty_first = 0;
@@ -321,7 +573,7 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
             n_ty = 2;
         }
         if (n_ty > 0)
-            k1_tiled<TILE_H, TILE_WO, TILE_THREADS><<<(unsigned)(p.tiles_x * n_ty), TILE_THREADS, lds_bytes, ctx->stream>>>(p);
+            hipLaunchKernelGGL(tv.kernel, dim3((unsigned)(p.tiles_x * n_ty)), dim3((unsigned)tv.threads), lds_bytes, ctx->stream, p);
         if (part != TSU_PART_INTERIOR) L->cur ^= 1;  // INTERIOR does not publish; BOUNDARY (or ALL) does
         done += k;
     }
