@@ -124,7 +124,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--L", type=int, default=4096)
     ap.add_argument("--sweeps-per-step", type=int, default=64)
-    ap.add_argument("--sweeps-per-launch", type=int, default=4)
+    ap.add_argument("--sweeps-per-launch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
@@ -219,7 +219,7 @@ def main():
             "dtype": "int8", "data": "synthetic (Philox i.i.d. +-1 start, seed 42)",
             "config": {"workload": f"IsingModel2D {L}x{L} per GPU at T_c=2.269185, J=1, h=0, periodic, checkerboard Gibbs sweep "
                                    "(BASELINE.json configs[1])", "L": L, "lattice_rows": L * world, "lattice_cols": L,
-                       "sweeps_per_step": sps, "sweeps_per_launch": k, "kernel": "k1_tiled (LDS halo tiles)",
+                       "sweeps_per_step": sps, "sweeps_per_launch": k, "kernel": "k1_tiled2 (LDS halo tiles, row-pair inner loop)",
                        "bias_mode": "physical", "parallelism": parallelism, "launches": n_launches},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

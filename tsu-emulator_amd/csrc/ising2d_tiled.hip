@@ -309,8 +309,8 @@ static __device__ __forceinline__ uint64_t pack_flags(const u32x4& d) {
 }
 
 // P0 = column parity of the updated colour in row tr_lo (and 1-P0 in the row below it)
-template <int NO, int RL, int P0, bool EDGE>
-static __device__ __forceinline__ void sweep_pairs(const Rows2Ctx& c, const PhiloxKeys& K, int al, int oct, uint32_t cq) {
+template <int NO, int P0, bool EDGE>
+static __device__ __forceinline__ void sweep_pairs(const Rows2Ctx& c, const PhiloxKeys& K, int al, int oct, uint32_t cq, int RL) {
     int idx = (c.tr_lo + 2 * al) * NO + oct;
     int rg = c.rgf + 2 * al;
 #pragma unroll 1
@@ -351,10 +351,16 @@ static __device__ __forceinline__ void sweep_pairs(const Rows2Ctx& c, const Phil
 template <int H, int WO, int THREADS>
 __global__ __launch_bounds__(THREADS) void k1_tiled2(TiledParams p) {
     constexpr int NO = WO + 2;
-    constexpr int RL = THREADS / NO;  // row lanes: threads [0, RL*NO) sweep, all threads load / store
+    constexpr int RLMAX = THREADS / NO;
     extern __shared__ uint64_t lds[];
     const int k = p.k;
     const int TR = H + 4 * k;
+    // Row lanes: threads [0, RL*NO) sweep (thread = one octet column x every RL-th row pair); all threads load and
+    // store.  A half-sweep costs ceil(npairs / RL) iterations per thread whatever the trapezoid removes, so RL is
+    // the smallest lane count that reaches the minimum iteration count (idle waves cost no VALU time).
+    const int npairs_max = (TR - 2) / 2;
+    const int n_iter = (npairs_max + RLMAX - 1) / RLMAX;
+    const int RL = (npairs_max + n_iter - 1) / n_iter;
     uint64_t* plane0 = lds + 1;
     uint64_t* plane1 = plane0 + TR * NO;
     uint64_t* s_thr = plane1 + TR * NO + NO + 1;  // one spare row: the pair loop reads row idx + 2 NO of the last pair
@@ -419,11 +425,11 @@ __global__ __launch_bounds__(THREADS) void k1_tiled2(TiledParams p) {
         const int par0 = (int)((p.row0 + Rb + c.tr_lo + kappa) & 1);
         if (al < RL) {
             if (edge) {
-                if (par0) sweep_pairs<NO, RL, 1, true>(c, K, al, oct, cq);
-                else sweep_pairs<NO, RL, 0, true>(c, K, al, oct, cq);
+                if (par0) sweep_pairs<NO, 1, true>(c, K, al, oct, cq, RL);
+                else sweep_pairs<NO, 0, true>(c, K, al, oct, cq, RL);
             } else {
-                if (par0) sweep_pairs<NO, RL, 1, false>(c, K, al, oct, cq);
-                else sweep_pairs<NO, RL, 0, false>(c, K, al, oct, cq);
+                if (par0) sweep_pairs<NO, 1, false>(c, K, al, oct, cq, RL);
+                else sweep_pairs<NO, 0, false>(c, K, al, oct, cq, RL);
             }
         }
     }
@@ -465,6 +471,11 @@ const TileVariant kVariants[] = {
     {128, 32, 512, k1_tiled2<128, 32, 512>},  // 8
     {128, 32, 1024, k1_tiled2<128, 32, 1024>},// 9
     {64, 32, 1024, k1_tiled2<64, 32, 1024>},  // 10
+    {64, 32, 576, k1_tiled2<64, 32, 576>},    // 11
+    {128, 32, 640, k1_tiled2<128, 32, 640>},  // 12
+    {128, 32, 832, k1_tiled2<128, 32, 832>},  // 13
+    {96, 32, 512, k1_tiled2<96, 32, 512>},    // 14
+    {96, 32, 768, k1_tiled2<96, 32, 768>},    // 15
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kMaxH = 128, kMaxNO = 66;
@@ -475,8 +486,18 @@ int pick_variant(const tsu_ising2d* L) {
         const char* e = getenv("TSU_TILE_VARIANT");
         env = e ? atoi(e) : -1;
     }
-    int v = env >= 0 && env < kNumVariants ? env : 1;
+    int v;
+    if (env >= 0 && env < kNumVariants) {
+        v = env;
+    } else {
+        // measured on MI355X (profiles/): 128-row tiles carry the least halo work; small lattices need all 16
+        // waves of a CU in one workgroup because they only have one tile per CU
+        const long long sites = (long long)L->rows * L->cols;
+        v = sites <= 4096ll * 4096ll ? 9 : 8;
+        if (L->rows < 256) v = 6;
+    }
     // a variant must fit the lattice (tile not wider than the lattice; single wrap of the global row index)
+    if (L->cols / 16 < kVariants[v].WO + 2 || L->total_rows < kVariants[v].H + 4 * KMAX) v = 6;
     if (L->cols / 16 < kVariants[v].WO + 2 || L->total_rows < kVariants[v].H + 4 * KMAX) v = 0;
     return v;
 }
@@ -505,7 +526,8 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
         TSU_HIP_TRY(ctx, hipMalloc(&L->alloc[1], bytes));
         TSU_HIP_TRY(ctx, hipMemsetAsync(L->alloc[1], 0, bytes, ctx->stream));
     }
-    int kmax = L->sweeps_per_launch > 0 ? L->sweeps_per_launch : 4;
+    // sweeps per launch: more sweeps amortise the tile load/store and the launch gap, fewer carry less halo work
+    int kmax = L->sweeps_per_launch > 0 ? L->sweeps_per_launch : ((long long)L->rows * L->cols <= 4096ll * 4096ll ? 8 : 4);
     if (kmax > KMAX) kmax = KMAX;
     if (!L->wrap_rows) {
         // ghost rows are only fresh for the first launch: all requested sweeps go into one launch
