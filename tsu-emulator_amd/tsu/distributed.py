@@ -67,7 +67,7 @@ class SlabLattice:
             # the library enqueues on torch's current stream so that RCCL ops and kernels are ordered by torch
             self.compute_stream = torch.cuda.current_stream(self.device_index)
             ctx.set_stream(self.compute_stream.cuda_stream)
-            self.comm_stream = torch.cuda.Stream(self.device_index) if (overlap and self.world > 1) else None
+            self.comm_stream = torch.cuda.Stream(self.device_index) if overlap else None
         else:
             self.ctx = None
             self.lat = engine(self.rows, self.cols, self.periodic, total_rows=self.total_rows, row0=self.rank * self.rows,
