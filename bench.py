@@ -124,7 +124,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--L", type=int, default=4096)
     ap.add_argument("--sweeps-per-step", type=int, default=64)
-    ap.add_argument("--sweeps-per-launch", type=int, default=8)
+    ap.add_argument("--sweeps-per-launch", type=int, default=0, help="0 = auto: 8 up to 4096^2 per GPU, 5 above")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
@@ -145,7 +145,8 @@ def main():
     from tsu.distributed import SlabLattice
     ctx = hip.Context(local_rank)
     hip.Context._default = ctx
-    L, k, sps = args.L, args.sweeps_per_launch, args.sweeps_per_step
+    L, sps = args.L, args.sweeps_per_step
+    k = args.sweeps_per_launch or (8 if L * L <= 4096 * 4096 else 5)
 
     if world == 1:
         lat = hip.Lattice(L, L, True, ctx=ctx)
@@ -235,8 +236,8 @@ def main():
         if not args.no_extra and world == 1:
             lat.close()
             extra = {}
-            for L2, k2 in ((8192, 4), (16384, 2)):
-                extra[f"ising2d_L{L2}"] = time_lattice(hip, ctx, L2, k2, 32)
+            for L2, k2 in ((8192, 5), (16384, 5)):
+                extra[f"ising2d_L{L2}"] = time_lattice(hip, ctx, L2, k2, 40)
             extra["langevin_dim_2^20"] = time_langevin(hip, ctx)
             extra["dense_gibbs"] = time_dense(hip, ctx)
             out["extra"] = extra

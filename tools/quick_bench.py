@@ -10,7 +10,7 @@ for L in Ls:
     lat = _hip.Lattice(L, L, True)
     lat.randomize(42)
     lat.set_model(1.0, 0.0, 2.269185)
-    for spl, n in ((2, 32), (4, 64), (8, 64)):
+    for spl, n in [(int(x), 60) for x in os.environ.get("KS", "3,4,5,6").split(",")]:
         lat.set_kernel(_hip.KERNEL_TILED, spl)
         lat.sweep(n, 1, sweep0=0)
         ctx.synchronize()

@@ -158,12 +158,14 @@ __global__ __launch_bounds__(256) void k1_generic(K1Params p, K1Table tbl, int c
 }
 
 // ------------------------------------------------------------------ K4: sum of spins, sum over bonds
+// grid-stride over (row, 16-byte chunk); per-thread int32 partials (|partial| <= 48 per chunk), wave shuffle +
+// LDS block reduce, ONE atomic pair per block (a 4096^2 lattice used to issue 262144 contended atomics).
 __global__ __launch_bounds__(256) void k4_observables(K1Params p, long long* __restrict__ acc) {
-    int q = blockIdx.x * 64 + threadIdx.x;
-    int r = blockIdx.y * 4 + threadIdx.y;
-    int nchunks = (p.cols + 15) >> 4;
-    int ss = 0, sb = 0;
-    if (q < nchunks && r < p.rows) {
+    const int nchunks = (p.cols + 15) >> 4;
+    const long long total = (long long)p.rows * nchunks;
+    long long ss = 0, sb = 0;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const int r = (int)(t / nchunks), q = (int)(t - (long long)r * nchunks);
         const int8_t* row = p.base + (long long)r * p.pitch;
         const int8_t* dn_row = nullptr;
         if (p.wrap_rows) dn_row = p.base + (long long)(r == p.rows - 1 ? 0 : r + 1) * p.pitch;
@@ -174,29 +176,36 @@ __global__ __launch_bounds__(256) void k4_observables(K1Params p, long long* __r
         if (16 * q + 16 < p.cols) next = row[16 * q + 16];
         else if (p.periodic && 16 * q + 16 == p.cols) next = row[0];
         uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w}, dw[4] = {dv.x, dv.y, dv.z, dv.w};
-        int s[17];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = (int8_t)((cw[i >> 2] >> (8 * (i & 3))) & 0xFF);
-        s[16] = next;
-        int last = p.cols - 16 * q;  // number of valid columns in this chunk (may exceed 16)
-        if (p.periodic && last < 16) s[last] = row[0];  // wrap bond of the last column inside a ragged chunk
+        const int last = p.cols - 16 * q;  // valid columns in this chunk (>= 16 except in a ragged last chunk)
+        const int wrap0 = (p.periodic && last < 16) ? (int)row[0] : 0;  // wrap bond of the last column, ragged chunk
+        int cs = 0, cb = 0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            int d = (int8_t)((dw[i >> 2] >> (8 * (i & 3))) & 0xFF);
+            const int si = (int8_t)((cw[i >> 2] >> (8 * (i & 3))) & 0xFF);
+            int sr = (i < 15) ? (int)(int8_t)((cw[(i + 1) >> 2] >> (8 * ((i + 1) & 3))) & 0xFF) : next;
+            if (i + 1 == last) sr = (last < 16) ? wrap0 : sr;
+            const int d = (int8_t)((dw[i >> 2] >> (8 * (i & 3))) & 0xFF);
             if (i < last) {
-                ss += s[i];
-                sb += s[i] * s[i + 1] + s[i] * d;
+                cs += si;
+                cb += si * sr + si * d;
             }
         }
+        ss += cs;
+        sb += cb;
     }
-    // wave reduce, then one atomic per wave
     for (int off = 32; off > 0; off >>= 1) {
         ss += __shfl_down(ss, off, 64);
         sb += __shfl_down(sb, off, 64);
     }
+    __shared__ long long part[2][4];
+    if ((threadIdx.x & 63) == 0) {
+        part[0][threadIdx.x >> 6] = ss;
+        part[1][threadIdx.x >> 6] = sb;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)(long long)ss);
-        atomicAdd(reinterpret_cast<unsigned long long*>(acc + 1), (unsigned long long)(long long)sb);
+        atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)(part[0][0] + part[0][1] + part[0][2] + part[0][3]));
+        atomicAdd(reinterpret_cast<unsigned long long*>(acc + 1), (unsigned long long)(part[1][0] + part[1][1] + part[1][2] + part[1][3]));
     }
 }
 
@@ -514,7 +523,9 @@ int tsu_ising2d_observables(tsu_ising2d* L, int64_t* sum_s, int64_t* sum_bonds) 
     TSU_REQUIRE(ctx, sum_s && sum_bonds, "ising2d_observables: NULL output");
     K1Params p = make_params(L, L->alloc[L->cur]);
     TSU_HIP_TRY(ctx, hipMemsetAsync(L->d_obs, 0, 2 * sizeof(int64_t), ctx->stream));
-    k4_observables<<<grid_for(L, L->rows), dim3(64, 4, 1), 0, ctx->stream>>>(p, (long long*)L->d_obs);
+    long long work = (long long)L->rows * ((L->cols + 15) / 16);
+    unsigned blocks = (unsigned)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096);
+    k4_observables<<<blocks, 256, 0, ctx->stream>>>(p, (long long*)L->d_obs);
     TSU_HIP_TRY(ctx, hipGetLastError());
     int64_t h[2];
     TSU_HIP_TRY(ctx, hipMemcpyAsync(h, L->d_obs, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));

@@ -348,8 +348,8 @@ static __device__ __forceinline__ void sweep_pairs(const Rows2Ctx& c, const Phil
     }
 }
 
-template <int H, int WO, int THREADS>
-__global__ __launch_bounds__(THREADS) void k1_tiled2(TiledParams p) {
+template <int H, int WO, int THREADS, int MINW = 1>
+__global__ __launch_bounds__(THREADS, MINW) void k1_tiled2(TiledParams p) {
     constexpr int NO = WO + 2;
     constexpr int RLMAX = THREADS / NO;
     extern __shared__ uint64_t lds[];
@@ -476,9 +476,16 @@ const TileVariant kVariants[] = {
     {128, 32, 832, k1_tiled2<128, 32, 832>},  // 13
     {96, 32, 512, k1_tiled2<96, 32, 512>},    // 14
     {96, 32, 768, k1_tiled2<96, 32, 768>},    // 15
+    {64, 32, 512, k1_tiled2<64, 32, 512, 6>},   // 16: <= 80 VGPRs -> 3 workgroups per CU
+    {64, 32, 512, k1_tiled2<64, 32, 512, 8>},   // 17: <= 64 VGPRs -> 4 workgroups per CU (LDS permitting)
+    {64, 32, 256, k1_tiled2<64, 32, 256, 8>},   // 18
+    {128, 32, 512, k1_tiled2<128, 32, 512, 6>}, // 19
+    {128, 32, 768, k1_tiled2<128, 32, 768, 6>}, // 20: 12 waves per workgroup, 2 workgroups per CU = 6 waves/SIMD
+    {128, 32, 640, k1_tiled2<128, 32, 640, 5>}, // 21
+    {256, 32, 1024, k1_tiled2<256, 32, 1024, 4>}, // 22: one 148 KB workgroup per CU
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
-constexpr int kMaxH = 128, kMaxNO = 66;
+constexpr int kMaxH = 256, kMaxNO = 66;
 
 int pick_variant(const tsu_ising2d* L) {
     static int env = -2;
@@ -527,7 +534,7 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
         TSU_HIP_TRY(ctx, hipMemsetAsync(L->alloc[1], 0, bytes, ctx->stream));
     }
     // sweeps per launch: more sweeps amortise the tile load/store and the launch gap, fewer carry less halo work
-    int kmax = L->sweeps_per_launch > 0 ? L->sweeps_per_launch : ((long long)L->rows * L->cols <= 4096ll * 4096ll ? 8 : 4);
+    int kmax = L->sweeps_per_launch > 0 ? L->sweeps_per_launch : ((long long)L->rows * L->cols <= 4096ll * 4096ll ? 8 : 5);
     if (kmax > KMAX) kmax = KMAX;
     if (!L->wrap_rows) {
         // ghost rows are only fresh for the first launch: all requested sweeps go into one launch
