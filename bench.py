@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--L", type=int, default=4096)
-    ap.add_argument("--sweeps-per-step", type=int, default=64)
+    ap.add_argument("--sweeps-per-step", type=int, default=0, help="0 = auto: the multiple of sweeps-per-launch nearest 64")
     ap.add_argument("--sweeps-per-launch", type=int, default=0, help="0 = auto: 8 up to 4096^2 per GPU, 5 above")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
@@ -145,8 +145,9 @@ def main():
     from tsu.distributed import SlabLattice
     ctx = hip.Context(local_rank)
     hip.Context._default = ctx
-    L, sps = args.L, args.sweeps_per_step
+    L = args.L
     k = args.sweeps_per_launch or (8 if L * L <= 4096 * 4096 else 5)
+    sps = args.sweeps_per_step or k * round(64 / k)
 
     if world == 1:
         lat = hip.Lattice(L, L, True, ctx=ctx)
@@ -194,10 +195,11 @@ def main():
 
     updates = float(L) * L * world * sps * args.steps
     value = updates / elapsed
-    n_launches = args.steps * ((sps + k - 1) // k) * (2 if (world > 1) else 1)
-    launches_for_bytes = args.steps * ((sps + k - 1) // k)
-    avg_launch_ms = ev_ms / launches_for_bytes
-    alg_bytes_per_launch = 2.0 * L * L * k  # 2 B per spin update (int8 read + write), k sweeps per launch, per GPU
+    n_launches = args.steps * ((sps + k - 1) // k)
+    avg_launch_ms = ev_ms / n_launches
+    # algorithmic bytes: 2 B per spin update (int8 read + write); a launch of k sweeps on this GPU's L x L sites
+    # carries 2 L^2 k bytes (the last launch of a step may be shorter, so average over the step)
+    alg_bytes_per_launch = 2.0 * L * L * sps / ((sps + k - 1) // k)
     achieved = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -221,7 +223,8 @@ def main():
             "config": {"workload": f"IsingModel2D {L}x{L} per GPU at T_c=2.269185, J=1, h=0, periodic, checkerboard Gibbs sweep "
                                    "(BASELINE.json configs[1])", "L": L, "lattice_rows": L * world, "lattice_cols": L,
                        "sweeps_per_step": sps, "sweeps_per_launch": k, "kernel": "k1_tiled2 (LDS halo tiles, row-pair inner loop)",
-                       "bias_mode": "physical", "parallelism": parallelism, "launches": n_launches},
+                       "bias_mode": "physical", "parallelism": parallelism, "launches": n_launches,
+                       "avg_launch_us": avg_launch_ms * 1e3, "algorithmic_bytes_per_launch": alg_bytes_per_launch},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "note": "achieved = algorithmic 2 B/spin-update x L^2 x k per launch / avg launch time (HIP events "

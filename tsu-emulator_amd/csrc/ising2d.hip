@@ -341,6 +341,9 @@ int tsu_ising2d_create_slab(tsu_ctx* ctx, int64_t total_rows, int cols, int peri
     L->sweeps_per_launch = 0;
     L->d_obs = nullptr;
     L->timed = 0;
+    L->d_sync = nullptr;
+    L->sync_cap = 0;
+    L->h_err = nullptr;
     size_t bytes = (size_t)(rows + 2 * ghost) * L->pitch;
     hipError_t e = hipMalloc(&L->alloc[0], bytes);
     if (e == hipSuccess) e = hipMemsetAsync(L->alloc[0], 0, bytes, ctx->stream);
@@ -369,6 +372,8 @@ int tsu_ising2d_destroy(tsu_ising2d* L) {
     for (int i = 0; i < 2; ++i)
         if (L->alloc[i]) (void)hipFree(L->alloc[i]);
     if (L->d_obs) (void)hipFree(L->d_obs);
+    if (L->d_sync) (void)hipFree(L->d_sync);
+    if (L->h_err) (void)hipHostFree(L->h_err);
     (void)hipEventDestroy(L->ev0);
     (void)hipEventDestroy(L->ev1);
     delete L;
@@ -389,6 +394,14 @@ int tsu_ising2d_set_spins(tsu_ising2d* L, const int8_t* host, int row_first, int
     return TSU_OK;
 }
 
+static int check_persist_error(tsu_ising2d* L) {
+    if (L->h_err && *L->h_err) {
+        *L->h_err = 0;
+        return tsu_fail(L->ctx, TSU_E_HIP, "ising2d: persistent sweep kernel timed out waiting for a neighbouring tile (results invalid)");
+    }
+    return TSU_OK;
+}
+
 int tsu_ising2d_get_spins(tsu_ising2d* L, int8_t* host, int row_first, int n_rows) {
     if (!L) return TSU_E_INVALID;
     tsu_ctx* ctx = L->ctx;
@@ -400,7 +413,7 @@ int tsu_ising2d_get_spins(tsu_ising2d* L, int8_t* host, int row_first, int n_row
     TSU_HIP_TRY(ctx, hipMemcpy2DAsync(host, (size_t)L->cols, src, L->pitch, (size_t)L->cols, (size_t)n_rows,
                                       hipMemcpyDeviceToHost, ctx->stream));
     TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return TSU_OK;
+    return check_persist_error(L);
 }
 
 int tsu_ising2d_randomize(tsu_ising2d* L, uint64_t seed, uint32_t replica) {
@@ -514,7 +527,7 @@ int tsu_ising2d_last_sweep_ms(tsu_ising2d* L, float* ms) {
     TSU_REQUIRE(L->ctx, L->timed, "ising2d_last_sweep_ms: no sweep has been timed yet");
     TSU_HIP_TRY(L->ctx, hipEventSynchronize(L->ev1));
     TSU_HIP_TRY(L->ctx, hipEventElapsedTime(ms, L->ev0, L->ev1));
-    return TSU_OK;
+    return check_persist_error(L);
 }
 
 int tsu_ising2d_observables(tsu_ising2d* L, int64_t* sum_s, int64_t* sum_bonds) {
@@ -532,7 +545,7 @@ int tsu_ising2d_observables(tsu_ising2d* L, int64_t* sum_s, int64_t* sum_bonds) 
     TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     *sum_s = h[0];
     *sum_bonds = h[1];
-    return TSU_OK;
+    return check_persist_error(L);
 }
 
 int tsu_ising2d_row_ptr(tsu_ising2d* L, int local_row, void** device_ptr, size_t* pitch_bytes) {

@@ -303,8 +303,10 @@ static __device__ __forceinline__ bool has_zero_field(const u32x4& d) {
 }
 
 static __device__ __forceinline__ uint64_t pack_flags(const u32x4& d) {
-    const uint32_t nlo = (perm(d.y, d.x, 0x07050301u) >> 7) & 0x01010101u;
-    const uint32_t nhi = (perm(d.w, d.z, 0x07050301u) >> 7) & 0x01010101u;
+    // v_perm_b32 selectors 8..11 replicate the sign bit of the four 16-bit fields of {S0,S1} (bits 15, 31, 47, 63)
+    // into a whole byte: one instruction turns the four "accept" signs into 0x00 / 0xFF bytes
+    const uint32_t nlo = perm(d.y, d.x, 0x0B0A0908u) & 0x01010101u;
+    const uint32_t nhi = perm(d.w, d.z, 0x0B0A0908u) & 0x01010101u;
     return (uint64_t)nlo | ((uint64_t)nhi << 32);
 }
 
@@ -348,12 +350,13 @@ static __device__ __forceinline__ void sweep_pairs(const Rows2Ctx& c, const Phil
     }
 }
 
-template <int H, int WO, int THREADS, int MINW = 1>
-__global__ __launch_bounds__(THREADS, MINW) void k1_tiled2(TiledParams p) {
+// one tile: HBM -> LDS planes, 2k half-sweeps, interior -> HBM (the other buffer)
+template <int H, int WO, int THREADS>
+static __device__ __forceinline__ void tile_body(const TiledParams& p, const int8_t* __restrict__ src, int8_t* __restrict__ dst,
+                                                 const int k, const uint32_t sweep0, const int tx, const int ty, uint64_t* lds,
+                                                 const PhiloxKeys& K) {
     constexpr int NO = WO + 2;
     constexpr int RLMAX = THREADS / NO;
-    extern __shared__ uint64_t lds[];
-    const int k = p.k;
     const int TR = H + 4 * k;
     // Row lanes: threads [0, RL*NO) sweep (thread = one octet column x every RL-th row pair); all threads load and
     // store.  A half-sweep costs ceil(npairs / RL) iterations per thread whatever the trapezoid removes, so RL is
@@ -367,7 +370,6 @@ __global__ __launch_bounds__(THREADS, MINW) void k1_tiled2(TiledParams p) {
     const int tid = threadIdx.x;
     if (tid < 5) s_thr[tid] = p.thr[tid];
 
-    const int tx = blockIdx.x % p.tiles_x, ty = p.ty_first + (blockIdx.x / p.tiles_x) * p.ty_stride;
     const int q0 = tx * WO, r0 = ty * H, Rb = r0 - 2 * k;
 
     for (int idx = tid; idx < (p.debug ? 0 : TR * NO); idx += THREADS) {
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k1_tiled2(TiledParams p) {
         if (cq < 0) cq += p.nchunks;
         if (cq >= p.nchunks) cq -= p.nchunks;
         if (cq >= p.nchunks) cq -= p.nchunks;
-        uint4 v = *reinterpret_cast<const uint4*>(p.src + (long long)srow * p.pitch + 16 * cq);
+        uint4 v = *reinterpret_cast<const uint4*>(src + (long long)srow * p.pitch + 16 * cq);
         uint32_t f0 = ((v.x >> 1) & 0x01010101u) ^ 0x01010101u, f1 = ((v.y >> 1) & 0x01010101u) ^ 0x01010101u;
         uint32_t f2 = ((v.z >> 1) & 0x01010101u) ^ 0x01010101u, f3 = ((v.w >> 1) & 0x01010101u) ^ 0x01010101u;
         uint64_t ev = (uint64_t)perm(f1, f0, 0x06040200u) | ((uint64_t)perm(f3, f2, 0x06040200u) << 32);
@@ -403,7 +405,6 @@ __global__ __launch_bounds__(THREADS, MINW) void k1_tiled2(TiledParams p) {
     if (cqi >= p.nchunks) cqi -= p.nchunks;
     if (cqi >= p.nchunks) cqi -= p.nchunks;
     const uint32_t cq = (uint32_t)cqi;
-    const PhiloxKeys K = make_keys(p.k0, p.k1);
 
     Rows2Ctx c;
     c.s_thr = s_thr;
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k1_tiled2(TiledParams p) {
     for (int hsi = 0; hsi < 2 * k; ++hsi) {
         __syncthreads();
         const int kappa = hsi & 1;
-        c.hs = 2u * (p.sweep0 + (uint32_t)(hsi >> 1)) + (uint32_t)kappa;
+        c.hs = 2u * (sweep0 + (uint32_t)(hsi >> 1)) + (uint32_t)kappa;
         c.Pd = kappa ? plane1 : plane0;
         c.Ps = kappa ? plane0 : plane1;
         c.tr_lo = 1 + hsi;
@@ -446,7 +447,89 @@ __global__ __launch_bounds__(THREADS, MINW) void k1_tiled2(TiledParams p) {
         uint32_t o0 = perm(0u, 0x000001FFu, (uint32_t)od), o1 = perm(0u, 0x000001FFu, (uint32_t)(od >> 32));
         uint4 v = make_uint4(perm(o0, e0, 0x05010400u), perm(o0, e0, 0x07030602u), perm(o1, e1, 0x05010400u),
                              perm(o1, e1, 0x07030602u));
-        *reinterpret_cast<uint4*>(p.dst + (long long)rl * p.pitch + 16 * cqs) = v;
+        *reinterpret_cast<uint4*>(dst + (long long)rl * p.pitch + 16 * cqs) = v;
+    }
+}
+
+template <int H, int WO, int THREADS, int MINW = 1>
+__global__ __launch_bounds__(THREADS, MINW) void k1_tiled2(TiledParams p) {
+    extern __shared__ uint64_t lds[];
+    const PhiloxKeys K = make_keys(p.k0, p.k1);
+    tile_body<H, WO, THREADS>(p, p.src, p.dst, p.k, p.sweep0, blockIdx.x % p.tiles_x,
+                              p.ty_first + (blockIdx.x / p.tiles_x) * p.ty_stride, lds, K);
+}
+
+// ------------------------------------------------------------------ persistent multi-generation kernel
+// One launch runs n_gen generations of k sweeps each over a whole periodic lattice (no slabs).  Work items are
+// (generation g, tile t), handed out by a global ticket counter in that order.  Item (g, t) reads buffer g & 1 and
+// writes buffer (g + 1) & 1; it may start once the 3 x 3 neighbourhood of t has finished generation g - 1, which is
+// also exactly the condition under which nobody still reads the region it will overwrite.  A workgroup only ever
+// waits for items with smaller tickets, which are finished or held by running workgroups: no deadlock for any grid
+// size.  Hand-off = the guide's release/acquire protocol: stores -> every wave s_waitcnt vmcnt(0) -> barrier ->
+// lane 0 agent release fence -> relaxed agent store of done[t]; consumer: relaxed agent polls (bounded) -> agent
+// acquire fence -> barrier -> plain loads.  This removes the launch gaps and the load-burst / tail of every launch.
+struct PersistParams {
+    TiledParams t;       // per-launch constants; src / dst / k / sweep0 are set per generation
+    int8_t* buf[2];      // owned row 0 of the two lattice buffers; generation g reads buf[(first + g) & 1]
+    int first;
+    int n_gen, k_last;   // generations of t.k sweeps, the last one of k_last sweeps
+    int tiles_y;
+    int* ticket;         // zeroed before the launch
+    int* done;           // [tiles]: number of generations finished, zeroed before the launch
+    int* err;            // set to 1 if a bounded wait expired
+};
+
+template <int H, int WO, int THREADS, int MINW = 1>
+__global__ __launch_bounds__(THREADS, MINW) void k1_persist(PersistParams P) {
+    extern __shared__ uint64_t lds[];
+    // the ticket is broadcast through the guard octet in front of plane 0 (only ever read as "octet -1" padding):
+    // a separate static __shared__ word would push two 80 KB workgroups past the CU's 160 KB
+    volatile int* s_ticket = reinterpret_cast<volatile int*>(lds);
+    const PhiloxKeys K = make_keys(P.t.k0, P.t.k1);
+    const int ntiles = P.t.tiles_x * P.tiles_y;
+    const int total = ntiles * P.n_gen;
+    const int tid = threadIdx.x;
+    while (true) {
+        __syncthreads();  // the previous tile's store phase has finished reading the LDS planes / s_ticket
+        if (tid == 0) *s_ticket = __hip_atomic_fetch_add(P.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int ticket = *s_ticket;
+        if (ticket >= total) break;
+        const int g = ticket / ntiles, t = ticket - g * ntiles;
+        const int tx = t % P.t.tiles_x, ty = t / P.t.tiles_x;
+        if (g > 0) {
+            // wait until the 3 x 3 neighbourhood (periodic in tiles) has finished generation g - 1
+            if (tid < 9) {
+                int nx = tx + (tid % 3) - 1, ny = ty + (tid / 3) - 1;
+                nx = nx < 0 ? nx + P.t.tiles_x : (nx >= P.t.tiles_x ? nx - P.t.tiles_x : nx);
+                ny = ny < 0 ? ny + P.tiles_y : (ny >= P.tiles_y ? ny - P.tiles_y : ny);
+                const int* flag = P.done + ny * P.t.tiles_x + nx;
+                int spins = 0;
+                while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1 << 22)) {  // ~seconds: never reached unless the protocol is broken
+                        __hip_atomic_store(P.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+        }
+        const int par = (P.first + g) & 1;
+        tile_body<H, WO, THREADS>(P.t, par ? P.buf[1] : P.buf[0], par ? P.buf[0] : P.buf[1], g == P.n_gen - 1 ? P.k_last : P.t.k,
+                                  P.t.sweep0 + (uint32_t)(g * P.t.k), tx, ty, lds, K);
+        // publish: this tile's stores are complete and visible before done[t] says so
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(P.done + t, g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -457,6 +540,7 @@ constexpr int KMAX = 8;  // one halo octet (16 columns) covers 2k <= 16 half-swe
 struct TileVariant {
     int H, WO, threads;
     void (*kernel)(TiledParams);
+    void (*persist)(PersistParams);  // multi-generation form (nullptr: not built for this shape)
 };
 // tile shapes compiled in; TSU_TILE_VARIANT (env, development aid) or tsu_ising2d_set_kernel picks one
 const TileVariant kVariants[] = {
@@ -466,26 +550,25 @@ const TileVariant kVariants[] = {
     {64, 64, 512, k1_tiled<64, 64, 512>},
     {32, 32, 256, k1_tiled<32, 32, 256>},
     {128, 32, 1024, k1_tiled<128, 32, 1024>},
-    {64, 32, 512, k1_tiled2<64, 32, 512>},    // 6: v2 inner loop (row pairs, VGPR keys)
+    {64, 32, 512, k1_tiled2<64, 32, 512>, k1_persist<64, 32, 512>},    // 6: v2 inner loop (row pairs, VGPR keys)
     {64, 32, 256, k1_tiled2<64, 32, 256>},    // 7
-    {128, 32, 512, k1_tiled2<128, 32, 512>},  // 8
-    {128, 32, 1024, k1_tiled2<128, 32, 1024>},// 9
+    {128, 32, 512, k1_tiled2<128, 32, 512>, k1_persist<128, 32, 512>},  // 8
+    {128, 32, 1024, k1_tiled2<128, 32, 1024>, k1_persist<128, 32, 1024>},// 9
     {64, 32, 1024, k1_tiled2<64, 32, 1024>},  // 10
     {64, 32, 576, k1_tiled2<64, 32, 576>},    // 11
     {128, 32, 640, k1_tiled2<128, 32, 640>},  // 12
     {128, 32, 832, k1_tiled2<128, 32, 832>},  // 13
     {96, 32, 512, k1_tiled2<96, 32, 512>},    // 14
     {96, 32, 768, k1_tiled2<96, 32, 768>},    // 15
-    {64, 32, 512, k1_tiled2<64, 32, 512, 6>},   // 16: <= 80 VGPRs -> 3 workgroups per CU
+    {64, 32, 512, k1_tiled2<64, 32, 512, 6>, k1_persist<64, 32, 512, 6>},   // 16: <= 80 VGPRs -> 3 workgroups per CU
     {64, 32, 512, k1_tiled2<64, 32, 512, 8>},   // 17: <= 64 VGPRs -> 4 workgroups per CU (LDS permitting)
     {64, 32, 256, k1_tiled2<64, 32, 256, 8>},   // 18
-    {128, 32, 512, k1_tiled2<128, 32, 512, 6>}, // 19
+    {128, 32, 512, k1_tiled2<128, 32, 512, 6>, k1_persist<128, 32, 512, 6>}, // 19
     {128, 32, 768, k1_tiled2<128, 32, 768, 6>}, // 20: 12 waves per workgroup, 2 workgroups per CU = 6 waves/SIMD
     {128, 32, 640, k1_tiled2<128, 32, 640, 5>}, // 21
     {256, 32, 1024, k1_tiled2<256, 32, 1024, 4>}, // 22: one 148 KB workgroup per CU
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
-constexpr int kMaxH = 256, kMaxNO = 66;
 
 int pick_variant(const tsu_ising2d* L) {
     static int env = -2;
@@ -581,6 +664,69 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
     if (!attr_set[&tv - kVariants]) {
         TSU_HIP_TRY(ctx, hipFuncSetAttribute((const void*)tv.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[&tv - kVariants] = true;
+    }
+    static int use_persist = -1;
+    if (use_persist < 0) {
+        // measured (profiles/r01_persistent_vs_launches.txt): the release/acquire hand-offs cost about what the launch
+        // gaps and load bursts cost, so one launch per generation stays the default; opt in with TSU_K1_PERSIST=1
+        const char* e = getenv("TSU_K1_PERSIST");
+        use_persist = e ? atoi(e) : 0;
+    }
+    if (use_persist && tv.persist && L->wrap_rows && part == TSU_PART_ALL && n_sweeps > kmax && !p.debug) {
+        // ---- one persistent launch for all generations (whole periodic lattice on this GPU)
+        const int vi = (int)(&tv - kVariants);
+        const int ntiles = p.tiles_x * tiles_y;
+        const size_t need = (size_t)ntiles + 1;
+        if (L->sync_cap < need) {
+            if (L->d_sync) (void)hipFree(L->d_sync);
+            L->d_sync = nullptr;
+            L->sync_cap = 0;
+            TSU_HIP_TRY(ctx, hipMalloc(&L->d_sync, need * sizeof(int)));
+            L->sync_cap = need;
+        }
+        if (!L->h_err) {
+            TSU_HIP_TRY(ctx, hipHostMalloc(&L->h_err, sizeof(int), hipHostMallocMapped));
+            *L->h_err = 0;
+        }
+        int* d_err = nullptr;
+        TSU_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&d_err, L->h_err, 0));
+        PersistParams P;
+        p.k = kmax;
+        p.sweep0 = sweep0;
+        p.ty_first = 0;
+        p.ty_stride = 1;
+        P.t = p;
+        P.buf[0] = L->alloc[0] + (size_t)L->ghost * L->pitch;
+        P.buf[1] = L->alloc[1] + (size_t)L->ghost * L->pitch;
+        P.first = L->cur;
+        P.n_gen = (n_sweeps + kmax - 1) / kmax;
+        P.k_last = n_sweeps - (P.n_gen - 1) * kmax;
+        P.tiles_y = tiles_y;
+        P.ticket = L->d_sync;
+        P.done = L->d_sync + 1;
+        P.err = d_err;
+        const int TRmax = TILE_H + 4 * kmax;
+        const size_t lds_bytes = ((size_t)2 * TRmax * TILE_NO + TILE_NO + 2 + 5) * sizeof(uint64_t);
+        static bool pattr[kNumVariants] = {};
+        static int resident[kNumVariants] = {};
+        if (!pattr[vi]) {
+            TSU_HIP_TRY(ctx, hipFuncSetAttribute((const void*)tv.persist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            pattr[vi] = true;
+        }
+        int per_cu = 0;
+        TSU_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)tv.persist, tv.threads, lds_bytes));
+        if (per_cu < 1) per_cu = 1;
+        if (getenv("TSU_K1_VERBOSE") && resident[vi] != per_cu)
+            fprintf(stderr, "[tsu] k1_persist variant %d: %d workgroups/CU, %zu B LDS, %d tiles x %d generations\n", vi, per_cu, lds_bytes, ntiles, P.n_gen);
+        resident[vi] = per_cu;
+        long long grid = (long long)per_cu * ctx->cus;
+        const long long items = (long long)ntiles * P.n_gen;
+        if (grid > items) grid = items;
+        TSU_HIP_TRY(ctx, hipMemsetAsync(L->d_sync, 0, need * sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(tv.persist, dim3((unsigned)grid), dim3((unsigned)tv.threads), lds_bytes, ctx->stream, P);
+        L->cur = (L->cur + P.n_gen) & 1;
+        TSU_HIP_TRY(ctx, hipGetLastError());
+        return TSU_OK;
     }
     for (int done = 0; done < n_sweeps;) {
         int k = n_sweeps - done < kmax ? n_sweeps - done : kmax;
