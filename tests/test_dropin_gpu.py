@@ -292,3 +292,33 @@ def test_core_sample_from_energy_quadratic_on_device_and_callable_on_host(golden
     assert set(np.unique(bits)) <= {0, 1} and abs(bits.mean() - 0.7) < 0.1
     cat = ThermalSamplingUnit(TSUConfig(n_burnin=5, n_steps=20)).sample_categorical([0.2, 0.5, 0.3], n_samples=20)
     assert cat.shape == (20,) and cat.min() >= 0 and cat.max() <= 2
+
+
+def test_temperature_scan_on_device_matches_onsager():
+    """f1: observables of GPU-resident lattices over a temperature scan, tiled kernel (640 columns)."""
+    from tsu.models import temperature_scan
+    Ts = [1.8, 2.0, 3.5]
+    r = temperature_scan((256, 640), Ts, n_equilibrate=400, n_measure=30, measure_every=10, seed=3)
+    onsager = [(1 - np.sinh(2 / T) ** -4) ** 0.125 for T in Ts[:2]]
+    assert abs(r["magnetization"][0] - onsager[0]) < 0.01 and abs(r["magnetization"][1] - onsager[1]) < 0.015
+    assert r["magnetization"][2] < 0.05                      # paramagnet
+    assert r["energy"][0] < r["energy"][1] < r["energy"][2] < -0.5
+    assert np.all(r["susceptibility"] >= 0) and np.all(r["specific_heat"] > 0)
+
+
+def test_lattice_replicas_are_independent_streams():
+    from tsu import _hip
+    from oracle import oracle as ora
+    table = ora.ising2d_thresholds(1.0, 0.0, 2.3, 0)
+    outs = []
+    for rep in (0, 1, 5):
+        lat = _hip.Lattice(128, 1024, True)
+        lat.randomize(11, replica=rep)
+        s0 = lat.get_spins()
+        np.testing.assert_array_equal(s0, ora.ising2d_randomize(128, 1024, 11, replica=rep))
+        lat.set_thresholds(table)
+        lat.sweep(9, 11, 0, replica=rep)
+        got = lat.get_spins()
+        np.testing.assert_array_equal(got, ora.ising2d_sweep(s0, True, table, 9, 11, 0, replica=rep))
+        outs.append(got)
+    assert (outs[0] != outs[1]).mean() > 0.2 and (outs[1] != outs[2]).mean() > 0.2

@@ -1,0 +1,13 @@
+import sys; sys.path.insert(0,"tsu-emulator_amd"); sys.path.insert(0,".")
+import numpy as np
+from tsu import _hip as hip
+ctx = hip.Context.default()
+n=4096
+rng = np.random.default_rng(42)
+G = rng.standard_normal((n, n)).astype(np.float32)
+J = ((G + G.T) / 2 / np.sqrt(n)).astype(np.float32)
+np.fill_diagonal(J, 0.0)
+d = hip.DenseSystem(J, None, hip.DTYPE_F32, ctx=ctx)
+d.set_state(rng.integers(0, 2, size=n).astype(np.int8))
+d.sweep(1.0, 3, seed=1, sweep0=0)
+ctx.synchronize()

@@ -18,6 +18,9 @@
 // Uniforms: replayed doubles from the host (bit-exact replay of np.random.rand) or Philox doubles keyed by
 // (site, sweep): a = W[2(i&1)] >> 5, b = W[2(i&1)+1] >> 6, u = (a 2^26 + b) / 2^53 with
 // W = Philox4x32-10(ctr = (i >> 1, 0, sweep, TAG_DENSE | replica << 8), key = seed).
+#include <algorithm>
+#include <vector>
+
 #include "tsu_common.h"
 
 #define DB 64  // block of visiting-order positions resolved by one wave
@@ -28,7 +31,8 @@ struct tsu_dense {
     void* J;    // n x n row-major, f64 or f32
     void* JT;   // transpose (aliases J when J is symmetric)
     double* bias;
-    int8_t* state;
+    int8_t* state;   // current state ({0,1})
+    int8_t* state2;  // next state: a sweep reads `state` (frozen) and writes `state2`, then the two are swapped
     double* field;
     int* flips;      // per block: [0] = count, [1..DB] = site, delta pairs packed (site << 1 | (delta > 0))
     int64_t* order;  // device copy of the visiting order (n_sweeps * n) or NULL
@@ -139,6 +143,108 @@ __global__ __launch_bounds__(256) void k2_propagate(const TJ* __restrict__ JT, d
     f[j] += acc;
 }
 
+// One block of 64 visiting-order positions per launch, ALL workgroups: every workgroup gathers the 64 x 64
+// sub-block and resolves the block redundantly (deterministic, so every copy agrees; the chain is latency-bound and
+// the other CUs would only wait), then applies the block's flips to its own slice of the remaining fields.  This
+// halves the launches of the resolve + propagate pair and removes the single-workgroup kernel from the chain.
+template <typename TJ>
+__global__ __launch_bounds__(256) void k2_block(const TJ* __restrict__ J, const TJ* __restrict__ JT,
+                                               const int8_t* __restrict__ s, int8_t* __restrict__ s_new,
+                                               double* __restrict__ f, const int64_t* __restrict__ order,
+                                               const double* __restrict__ uniforms, int n, int pos0, int cnt, double T,
+                                               uint32_t sweep, uint32_t tag, uint32_t k0, uint32_t k1, int last_block) {
+    __shared__ double sub[DB][DB + 1];  // sub[i][k] = J[site_k][site_i]
+    __shared__ int sites[DB];
+    __shared__ int sh_flips[DB];
+    __shared__ int sh_nflip;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < DB) sites[tid] = tid < cnt ? (order ? (int)order[pos0 + tid] : pos0 + tid) : -1;
+    __syncthreads();
+    // gather: thread (wave, lane) loads rows i = wave, wave + 4, ... for column site_lane; all 16 loads are issued
+    // before the first one is consumed (one L2/HBM latency per block instead of sixteen)
+    {
+        const int site = sites[lane];
+        TJ v[DB / 4];
+#pragma unroll
+        for (int r = 0; r < DB / 4; ++r) {
+            const int i = wave + 4 * r;
+            v[r] = (lane < cnt && i < cnt) ? J[(size_t)site * n + sites[i]] : (TJ)0;
+        }
+#pragma unroll
+        for (int r = 0; r < DB / 4; ++r) {
+            const int i = wave + 4 * r;
+            if (lane < cnt && i < cnt) sub[i][lane] = (double)v[r];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int site = sites[lane];
+        double fk = 0.0, u = 2.0;
+        int bit = 0;
+        if (lane < cnt) {
+            fk = f[site];
+            bit = s[site];
+            u = uniforms ? uniforms[pos0 + lane] : dense_uniform((uint32_t)site, sweep, tag, k0, k1);
+        }
+        // u < sigmoid(x) <=> x > logit(u): the logit is computed once per site, so the flip-to-flip chain below
+        // carries one compare instead of a float64 exp.  The reference's own expression decides whenever x is
+        // within a safety margin of the logit (and beyond the +-20 clamp, gibbs.py:73-76), so outcomes are unchanged.
+        const double logit = (lane < cnt) ? (log(u) - log1p(-u)) : 0.0;
+        const double margin = 1e-9 * (1.0 + fabs(logit));
+        int nflip = 0, cursor = 0;
+        const double invT = 1.0 / T;
+        while (true) {
+            const double xa = fk * invT;  // approximate x = fk / T: only used where it is decisive by a wide margin
+            int cand;
+            if (fabs(fabs(xa) - 20.0) < 1e-9 || fabs(xa - logit) <= margin) cand = (u < sigmoid_clamped(fk / T)) ? 1 : 0;
+            else if (xa > 20.0) cand = 1;  // p = 1.0 > u
+            else if (xa < -20.0) cand = 0;
+            else cand = xa > logit ? 1 : 0;
+            if (lane >= cnt) cand = 0;
+            unsigned long long want = __ballot((lane >= cursor) && (lane < cnt) && (cand != bit));
+            if (want == 0ull) break;
+            int i = __ffsll((long long)want) - 1;
+            int delta = __shfl(cand - bit, i, 64);
+            if (lane == i) bit = cand;
+            if (lane < cnt) fk += (double)delta * sub[i][lane];
+            if (lane == 0) sh_flips[nflip] = (sites[i] << 1) | (delta > 0 ? 1 : 0);
+            ++nflip;
+            cursor = i + 1;
+        }
+        if (lane == 0) sh_nflip = nflip;
+        // one copy publishes the block's new bits -- into the NEXT-state array: the other workgroups may still be
+        // reading this block's old bits.  The block's own fields are not needed again before the next sweep's
+        // field pass, and nobody writes them during this launch (the slice update below skips the block).
+        if (blockIdx.x == 0 && lane < cnt) s_new[site] = (int8_t)bit;
+    }
+    __syncthreads();
+    const int nflip = sh_nflip;
+    if (nflip == 0 || last_block) return;
+    for (int j = blockIdx.x * blockDim.x + tid; j < n; j += gridDim.x * blockDim.x) {
+        bool inside = false;
+        if (!order) inside = (j >= pos0 && j < pos0 + cnt);
+        else
+            for (int k = 0; k < cnt; ++k) inside |= (sites[k] == j);
+        if (inside) continue;
+        // eight independent loads in flight per step: the flips are few (tens), so this loop is latency-bound
+        double acc = 0.0;
+        for (int k0 = 0; k0 < nflip; k0 += 8) {
+            TJ v[8];
+            double w[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k = k0 + q < nflip ? k0 + q : nflip - 1;
+                const int fl = sh_flips[k];
+                v[q] = JT[(size_t)(fl >> 1) * n + j];
+                w[q] = k0 + q < nflip ? ((fl & 1) ? 1.0 : -1.0) : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += w[q] * (double)v[q];
+        }
+        f[j] += acc;
+    }
+}
+
 __global__ __launch_bounds__(256) void k2_energy(const double* __restrict__ f, const int8_t* __restrict__ s,
                                                 const double* __restrict__ bias, double* __restrict__ out, int n) {
     // f = J s + b  =>  -1/2 s.(f - b) - b.s
@@ -164,16 +270,21 @@ static int dense_sweep_impl(tsu_dense* d, double T, int n_sweeps, bool have_orde
     uint32_t tag = TSU_TAG_DENSE | (replica << 8);
     unsigned mv_grid = (unsigned)(((size_t)n * 64 + 255) / 256), pg_grid = (unsigned)((n + 255) / 256);
     for (int s = 0; s < n_sweeps; ++s) {
+        TSU_HIP_TRY(ctx, hipMemcpyAsync(d->state2, d->state, (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
         k2_matvec<TJ><<<mv_grid, 256, 0, ctx->stream>>>(J, d->state, d->bias, d->field, n);
         const int64_t* ord = have_order ? d->order + (size_t)s * n : nullptr;
         const double* uni = have_uni ? d->uniforms + (size_t)s * n : nullptr;
+        unsigned blk_grid = pg_grid < (unsigned)(2 * ctx->cus) ? pg_grid : (unsigned)(2 * ctx->cus);
         for (int pos0 = 0; pos0 < n; pos0 += DB) {
             int cnt = n - pos0 < DB ? n - pos0 : DB;
-            k2_resolve<TJ><<<1, 64, 0, ctx->stream>>>(J, d->state, d->field, ord, uni ? uni : nullptr, d->flips, n, pos0, cnt,
-                                                      T, sweep0 + (uint32_t)s, tag, (uint32_t)seed, (uint32_t)(seed >> 32));
-            if (pos0 + cnt < n)
-                k2_propagate<TJ><<<pg_grid, 256, 0, ctx->stream>>>(JT, d->field, d->flips, ord, n, pos0, cnt);
+            int last = pos0 + cnt >= n;
+            k2_block<TJ><<<last ? 1u : blk_grid, 256, 0, ctx->stream>>>(J, JT, d->state, d->state2, d->field, ord, uni, n, pos0,
+                                                                       cnt, T, sweep0 + (uint32_t)s, tag, (uint32_t)seed,
+                                                                       (uint32_t)(seed >> 32), last);
         }
+        int8_t* t = d->state;
+        d->state = d->state2;
+        d->state2 = t;
     }
     TSU_HIP_TRY(ctx, hipGetLastError());
     return TSU_OK;
@@ -232,6 +343,7 @@ int tsu_dense_create(tsu_ctx* ctx, int n, const void* J_host, int dtype, const d
     }
     if (e == hipSuccess) e = hipMalloc(&d->state, (size_t)n);
     if (e == hipSuccess) e = hipMemsetAsync(d->state, 0, (size_t)n, ctx->stream);
+    if (e == hipSuccess) e = hipMalloc(&d->state2, (size_t)n);
     if (e == hipSuccess) e = hipMalloc(&d->field, (size_t)n * 8);
     if (e == hipSuccess) e = hipMalloc(&d->flips, (DB + 1) * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&d->d_energy, 8);
@@ -253,6 +365,7 @@ int tsu_dense_destroy(tsu_dense* d) {
     if (d->J) (void)hipFree(d->J);
     if (d->bias) (void)hipFree(d->bias);
     if (d->state) (void)hipFree(d->state);
+    if (d->state2) (void)hipFree(d->state2);
     if (d->field) (void)hipFree(d->field);
     if (d->flips) (void)hipFree(d->flips);
     if (d->order) (void)hipFree(d->order);
@@ -288,8 +401,17 @@ int tsu_dense_sweep(tsu_dense* d, double T, int n_sweeps, const int64_t* order, 
     if (n_sweeps == 0) return TSU_OK;
     size_t cnt = (size_t)n_sweeps * d->n;
     if (order) {
-        for (size_t i = 0; i < cnt; ++i)
-            TSU_REQUIRE(ctx, order[i] >= 0 && order[i] < d->n, "dense_sweep: order[%zu] = %lld out of range", i, (long long)order[i]);
+        // every sweep must visit every site exactly once (np.random.permutation, gibbs.py:157): the sweep reads the
+        // frozen current state for "old" bits, which is only right for a site's first visit
+        std::vector<char> seen((size_t)d->n);
+        for (int sw = 0; sw < n_sweeps; ++sw) {
+            std::fill(seen.begin(), seen.end(), 0);
+            for (int i = 0; i < d->n; ++i) {
+                long long v = order[(size_t)sw * d->n + i];
+                TSU_REQUIRE(ctx, v >= 0 && v < d->n && !seen[(size_t)v], "dense_sweep: order row %d is not a permutation of 0..%d", sw, d->n - 1);
+                seen[(size_t)v] = 1;
+            }
+        }
         if (d->order_cap < cnt) {
             if (d->order) (void)hipFree(d->order);
             d->order = nullptr;

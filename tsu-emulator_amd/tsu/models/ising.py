@@ -421,3 +421,32 @@ def demonstrate_phase_transition(sizes: List[int] = [8, 16, 32], temperatures: O
             "specific_heats": np.array(specific_heats),
         }
     return results
+
+
+def temperature_scan(size, temperatures, coupling: float = 1.0, n_equilibrate: int = 1000, n_measure: int = 50,
+                     measure_every: int = 10, periodic: bool = True, seed: int = 0, bias_mode: str = "physical",
+                     initial: str = "up") -> dict:
+    """GPU-resident form of :func:`demonstrate_phase_transition` (reference: ising.py:424-476) for lattices far
+    beyond what a samples array can hold: one :class:`IsingModel2D` per temperature stays on the device, and
+    |M|, E/N, chi = (<M^2> - <M>^2) N / T and C = (<E^2> - <E>^2) / (T^2 N) come from the device reductions
+    (``tsu_ising2d_observables``) -- no spin ever crosses PCIe.  Returns arrays indexed like ``temperatures``.
+    """
+    temperatures = np.asarray(temperatures, dtype=float)
+    out = {k: np.zeros(len(temperatures)) for k in ("magnetization", "energy", "susceptibility", "specific_heat")}
+    out["temperatures"] = temperatures
+    for i, T in enumerate(temperatures):
+        m = IsingModel2D(size, coupling=coupling, temperature=float(T), periodic=periodic, seed=seed + i,
+                         bias_mode=bias_mode, initial=initial)
+        m.equilibrate(n_sweeps=n_equilibrate)
+        Ms, Es = np.zeros(n_measure), np.zeros(n_measure)
+        for j in range(n_measure):
+            m.gibbs_update(measure_every)
+            Ms[j] = m.magnetization()
+            Es[j] = m.energy()
+        N = m.n_spins
+        out["magnetization"][i] = np.mean(np.abs(Ms))
+        out["energy"][i] = np.mean(Es) / N
+        out["susceptibility"][i] = (np.mean(Ms ** 2) - np.mean(np.abs(Ms)) ** 2) * N / T
+        out["specific_heat"][i] = (np.mean(Es ** 2) - np.mean(Es) ** 2) / (T ** 2 * N)
+        del m
+    return out
