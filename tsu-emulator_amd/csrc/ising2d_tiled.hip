@@ -263,8 +263,8 @@ static __device__ __forceinline__ u32x4 philox_vk(uint32_t c0, uint32_t c1, uint
     for (int r = 0; r < 10; ++r) {
         uint64_t p0 = (uint64_t)TSU_PHILOX_M0 * c0;
         uint64_t p1 = (uint64_t)TSU_PHILOX_M1 * c2;
-        uint32_t n0 = ((uint32_t)(p1 >> 32) ^ c1) ^ K.a[r];
-        uint32_t n2 = ((uint32_t)(p0 >> 32) ^ c3) ^ K.b[r];
+        uint32_t n0 = tsu_xor3((uint32_t)(p1 >> 32), c1, K.a[r]);
+        uint32_t n2 = tsu_xor3((uint32_t)(p0 >> 32), c3, K.b[r]);
         c1 = (uint32_t)p1;
         c3 = (uint32_t)p0;
         c0 = n0;
@@ -317,9 +317,20 @@ static __device__ __forceinline__ void sweep_pairs(const Rows2Ctx& c, const Phil
     int rg = c.rgf + 2 * al;
 #pragma unroll 1
     for (int a = al; a < c.npairs; a += RL, idx += 2 * RL * NO, rg += 2 * RL) {
+        // issue the six LDS reads, run the two Philox blocks (which do not depend on them) while they are in flight,
+        // and only then consume the neighbour rows
         const uint64_t R0 = c.Ps[idx - NO], R1 = c.Ps[idx], R2 = c.Ps[idx + NO], R3 = c.Ps[idx + 2 * NO];
         const uint32_t A0 = reinterpret_cast<const uint32_t*>(c.Ps)[2 * idx + (P0 ? 2 : -1)];
         const uint32_t A1 = reinterpret_cast<const uint32_t*>(c.Ps)[2 * (idx + NO) + (P0 ? -1 : 2)];
+        __builtin_amdgcn_sched_barrier(0);  // the reads stay above the Philox blocks ...
+        int rga = rg, rgb = rg + 1;
+        if (EDGE) {
+            if (rga >= c.total_rows) rga -= c.total_rows;
+            if (rgb >= c.total_rows) rgb -= c.total_rows;
+        }
+        const u32x4 w0 = philox_vk(cq, (uint32_t)rga, c.hs, c.tag_hi, K);
+        const u32x4 w1 = philox_vk(cq, (uint32_t)rgb, c.hs, c.tag_hi, K);
+        __builtin_amdgcn_sched_barrier(0);  // ... and their first use stays below
         const uint32_t C0l = (uint32_t)R1, C0h = (uint32_t)(R1 >> 32), C1l = (uint32_t)R2, C1h = (uint32_t)(R2 >> 32);
         // horizontal neighbours: compact bytes (j, j+1) when the parity is 1, (j-1, j) when it is 0
         const uint32_t S0l = P0 ? __builtin_amdgcn_alignbyte(C0h, C0l, 1) : __builtin_amdgcn_alignbyte(C0l, A0, 3);
@@ -330,14 +341,6 @@ static __device__ __forceinline__ void sweep_pairs(const Rows2Ctx& c, const Phil
         const uint32_t ml = C0l + C1l, mh = C0h + C1h;
         const uint32_t cnt0l = (uint32_t)R0 + ml + S0l, cnt0h = (uint32_t)(R0 >> 32) + mh + S0h;
         const uint32_t cnt1l = (uint32_t)R3 + ml + S1l, cnt1h = (uint32_t)(R3 >> 32) + mh + S1h;
-
-        int rga = rg, rgb = rg + 1;
-        if (EDGE) {
-            if (rga >= c.total_rows) rga -= c.total_rows;
-            if (rgb >= c.total_rows) rgb -= c.total_rows;
-        }
-        const u32x4 w0 = philox_vk(cq, (uint32_t)rga, c.hs, c.tag_hi, K);
-        const u32x4 w1 = philox_vk(cq, (uint32_t)rgb, c.hs, c.tag_hi, K);
         u32x4 d0 = compare_octet(w0, cnt0l, cnt0h, c.tblH0, c.tblH1, c.tblL0, c.tblL1);
         u32x4 d1 = compare_octet(w1, cnt1l, cnt1h, c.tblH0, c.tblH1, c.tblL0, c.tblL1);
         const uint32_t mn = minu16(minu16(minu16(d0.x, d0.y), minu16(d0.z, d0.w)), minu16(minu16(d1.x, d1.y), minu16(d1.z, d1.w)));
@@ -410,7 +413,12 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
     c.s_thr = s_thr;
     c.total_rows = (int)p.total_rows;
     c.tag_hi = p.tag_hi; c.tag_lo = p.tag_lo; c.k0 = p.k0; c.k1 = p.k1;
+    // the threshold byte tables live in VGPRs: v_perm_b32 may read only one SGPR, so SGPR tables cost a v_mov per use
     c.tblH0 = p.tblH0; c.tblH1 = p.tblH1; c.tblL0 = p.tblL0; c.tblL1 = p.tblL1;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(c.tblH0) : "s"(p.tblH0));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(c.tblH1) : "s"(p.tblH1));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(c.tblL0) : "s"(p.tblL0));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(c.tblL1) : "s"(p.tblL1));
 
     for (int hsi = 0; hsi < 2 * k; ++hsi) {
         __syncthreads();
