@@ -313,15 +313,24 @@ static __device__ __forceinline__ uint64_t pack_flags(const u32x4& d) {
 // P0 = column parity of the updated colour in row tr_lo (and 1-P0 in the row below it)
 template <int NO, int P0, bool EDGE>
 static __device__ __forceinline__ void sweep_pairs(const Rows2Ctx& c, const PhiloxKeys& K, int al, int oct, uint32_t cq, int RL) {
-    int idx = (c.tr_lo + 2 * al) * NO + oct;
+    // One byte offset into the source plane and one row counter are the only induction variables (kept opaque so
+    // that the compiler does not re-derive them from a separate trip counter); everything else is an immediate.
+    const char* const ps0 = reinterpret_cast<const char*>(c.Ps);
+    const int d_off = (int)(reinterpret_cast<const char*>(c.Pd) - ps0);
+    const int off_end = (c.tr_lo + 2 * c.npairs) * NO * 8;
+    const int off_step = 2 * RL * NO * 8;
+    int off = ((c.tr_lo + 2 * al) * NO + oct) * 8;
     int rg = c.rgf + 2 * al;
 #pragma unroll 1
-    for (int a = al; a < c.npairs; a += RL, idx += 2 * RL * NO, rg += 2 * RL) {
+    for (; off < off_end; off += off_step, rg += 2 * RL) {
+        asm volatile("" : "+v"(off), "+v"(rg));
         // issue the six LDS reads, run the two Philox blocks (which do not depend on them) while they are in flight,
         // and only then consume the neighbour rows
-        const uint64_t R0 = c.Ps[idx - NO], R1 = c.Ps[idx], R2 = c.Ps[idx + NO], R3 = c.Ps[idx + 2 * NO];
-        const uint32_t A0 = reinterpret_cast<const uint32_t*>(c.Ps)[2 * idx + (P0 ? 2 : -1)];
-        const uint32_t A1 = reinterpret_cast<const uint32_t*>(c.Ps)[2 * (idx + NO) + (P0 ? -1 : 2)];
+        const char* ps = ps0 + off;
+        const uint64_t R0 = *reinterpret_cast<const uint64_t*>(ps - NO * 8), R1 = *reinterpret_cast<const uint64_t*>(ps);
+        const uint64_t R2 = *reinterpret_cast<const uint64_t*>(ps + NO * 8), R3 = *reinterpret_cast<const uint64_t*>(ps + 2 * NO * 8);
+        const uint32_t A0 = *reinterpret_cast<const uint32_t*>(ps + (P0 ? 8 : -4));
+        const uint32_t A1 = *reinterpret_cast<const uint32_t*>(ps + NO * 8 + (P0 ? -4 : 8));
         __builtin_amdgcn_sched_barrier(0);  // the reads stay above the Philox blocks ...
         int rga = rg, rgb = rg + 1;
         if (EDGE) {
@@ -348,8 +357,9 @@ static __device__ __forceinline__ void sweep_pairs(const Rows2Ctx& c, const Phil
             if (has_zero_field(d0)) d0 = resolve_ties(d0, w0, cnt0l, cnt0h, c.s_thr, cq, (uint32_t)rga, c.hs, c.tag_lo, c.k0, c.k1);
             if (has_zero_field(d1)) d1 = resolve_ties(d1, w1, cnt1l, cnt1h, c.s_thr, cq, (uint32_t)rgb, c.hs, c.tag_lo, c.k0, c.k1);
         }
-        c.Pd[idx] = pack_flags(d0);
-        c.Pd[idx + NO] = pack_flags(d1);
+        char* pd = const_cast<char*>(ps) + d_off;
+        *reinterpret_cast<uint64_t*>(pd) = pack_flags(d0);
+        *reinterpret_cast<uint64_t*>(pd + NO * 8) = pack_flags(d1);
     }
 }
 
@@ -375,39 +385,39 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
 
     const int q0 = tx * WO, r0 = ty * H, Rb = r0 - 2 * k;
 
-    for (int idx = tid; idx < (p.debug ? 0 : TR * NO); idx += THREADS) {
-        int tr = idx / NO, oct = idx - tr * NO;
-        int rl = Rb + tr;
-        int srow;
-        if (p.wrap_rows) {
-            srow = rl % p.rows;
-            if (srow < 0) srow += p.rows;
-        } else {
-            srow = rl < -p.ghost ? -p.ghost : (rl >= p.rows + p.ghost ? p.rows + p.ghost - 1 : rl);
-        }
-        int cq = q0 - 1 + oct;
-        if (cq < 0) cq += p.nchunks;
-        if (cq >= p.nchunks) cq -= p.nchunks;
-        if (cq >= p.nchunks) cq -= p.nchunks;
-        uint4 v = *reinterpret_cast<const uint4*>(src + (long long)srow * p.pitch + 16 * cq);
-        uint32_t f0 = ((v.x >> 1) & 0x01010101u) ^ 0x01010101u, f1 = ((v.y >> 1) & 0x01010101u) ^ 0x01010101u;
-        uint32_t f2 = ((v.z >> 1) & 0x01010101u) ^ 0x01010101u, f3 = ((v.w >> 1) & 0x01010101u) ^ 0x01010101u;
-        uint64_t ev = (uint64_t)perm(f1, f0, 0x06040200u) | ((uint64_t)perm(f3, f2, 0x06040200u) << 32);
-        uint64_t od = (uint64_t)perm(f1, f0, 0x07050301u) | ((uint64_t)perm(f3, f2, 0x07050301u) << 32);
-        int gpar = (int)((p.row0 + rl) & 1);
-        (gpar ? plane1 : plane0)[idx] = ev;
-        (gpar ? plane0 : plane1)[idx] = od;
-    }
-
-    long long rg0 = (p.row0 + Rb) % p.total_rows;
-    if (rg0 < 0) rg0 += p.total_rows;
-    const bool edge = (rg0 + TR > p.total_rows);
+    // a thread owns one octet column (al = row lane, oct = column) in all three phases: no div/mod in any loop
     const int al = tid / NO, oct = tid - al * NO;
     int cqi = q0 - 1 + oct;
     if (cqi < 0) cqi += p.nchunks;
     if (cqi >= p.nchunks) cqi -= p.nchunks;
     if (cqi >= p.nchunks) cqi -= p.nchunks;
     const uint32_t cq = (uint32_t)cqi;
+
+    if (!p.debug && al < RLMAX) {
+        const int8_t* col = src + 16 * (long long)cq;
+        int gpar = (int)((p.row0 + Rb + al) & 1);  // colour of the even columns of row tr
+#pragma unroll 2
+        for (int tr = al; tr < TR; tr += RLMAX) {
+            const int rl = Rb + tr;
+            int srow;
+            if (p.wrap_rows) srow = rl < 0 ? rl + p.rows : (rl >= p.rows ? rl - p.rows : rl);  // rows >= TR: one wrap
+            else srow = rl < -p.ghost ? -p.ghost : (rl >= p.rows + p.ghost ? p.rows + p.ghost - 1 : rl);
+            const uint4 v = *reinterpret_cast<const uint4*>(col + (long long)srow * p.pitch);
+            // de-interleave the two colours, then +1 (0x01) -> 1, -1 (0xFF) -> 0: bit 1 of the byte, inverted
+            const uint32_t e0 = perm(v.y, v.x, 0x06040200u), e1 = perm(v.w, v.z, 0x06040200u);
+            const uint32_t o0 = perm(v.y, v.x, 0x07050301u), o1 = perm(v.w, v.z, 0x07050301u);
+            const uint64_t ev = (uint64_t)(~(e0 >> 1) & 0x01010101u) | ((uint64_t)(~(e1 >> 1) & 0x01010101u) << 32);
+            const uint64_t od = (uint64_t)(~(o0 >> 1) & 0x01010101u) | ((uint64_t)(~(o1 >> 1) & 0x01010101u) << 32);
+            const int idx = tr * NO + oct;
+            (gpar ? plane1 : plane0)[idx] = ev;
+            (gpar ? plane0 : plane1)[idx] = od;
+            if (RLMAX & 1) gpar ^= 1;
+        }
+    }
+
+    long long rg0 = (p.row0 + Rb) % p.total_rows;
+    if (rg0 < 0) rg0 += p.total_rows;
+    const bool edge = (rg0 + TR > p.total_rows);
 
     Rows2Ctx c;
     c.s_thr = s_thr;
@@ -444,18 +454,25 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
     }
     __syncthreads();
 
-    for (int idx = tid; idx < (p.debug >= 2 ? 0 : H * WO); idx += THREADS) {
-        int hr = idx / WO, oc = idx - hr * WO + 1;
-        int rl = r0 + hr, cqs = q0 + oc - 1;
-        if (rl >= p.rows || cqs >= p.nchunks) continue;
-        int li = (2 * k + hr) * NO + oc;
-        int gpar = (int)((p.row0 + rl) & 1);
-        uint64_t ev = (gpar ? plane1 : plane0)[li], od = (gpar ? plane0 : plane1)[li];
-        uint32_t e0 = perm(0u, 0x000001FFu, (uint32_t)ev), e1 = perm(0u, 0x000001FFu, (uint32_t)(ev >> 32));
-        uint32_t o0 = perm(0u, 0x000001FFu, (uint32_t)od), o1 = perm(0u, 0x000001FFu, (uint32_t)(od >> 32));
-        uint4 v = make_uint4(perm(o0, e0, 0x05010400u), perm(o0, e0, 0x07030602u), perm(o1, e1, 0x05010400u),
-                             perm(o1, e1, 0x07030602u));
-        *reinterpret_cast<uint4*>(dst + (long long)rl * p.pitch + 16 * cqs) = v;
+    // interior octets are tile columns 1 .. NO-2: the same thread -> column mapping, halo columns idle
+    if (p.debug < 2 && al < RLMAX && oct >= 1 && oct <= WO && q0 + oct - 1 < p.nchunks) {
+        int8_t* col = dst + 16 * (long long)(q0 + oct - 1);
+        int gpar = (int)((p.row0 + r0 + al) & 1);
+#pragma unroll 2
+        for (int hr = al; hr < H; hr += RLMAX) {
+            const int rl = r0 + hr;
+            if (rl < p.rows) {
+                const int li = (2 * k + hr) * NO + oct;
+                const uint64_t ev = (gpar ? plane1 : plane0)[li], od = (gpar ? plane0 : plane1)[li];
+                // up flag -> spin byte: 1 -> 0x01, 0 -> 0xFF
+                const uint32_t e0 = perm(0u, 0x000001FFu, (uint32_t)ev), e1 = perm(0u, 0x000001FFu, (uint32_t)(ev >> 32));
+                const uint32_t o0 = perm(0u, 0x000001FFu, (uint32_t)od), o1 = perm(0u, 0x000001FFu, (uint32_t)(od >> 32));
+                const uint4 v = make_uint4(perm(o0, e0, 0x05010400u), perm(o0, e0, 0x07030602u), perm(o1, e1, 0x05010400u),
+                                           perm(o1, e1, 0x07030602u));
+                *reinterpret_cast<uint4*>(col + (long long)rl * p.pitch) = v;
+            }
+            if (RLMAX & 1) gpar ^= 1;
+        }
     }
 }
 
@@ -575,6 +592,10 @@ const TileVariant kVariants[] = {
     {128, 32, 768, k1_tiled2<128, 32, 768, 6>}, // 20: 12 waves per workgroup, 2 workgroups per CU = 6 waves/SIMD
     {128, 32, 640, k1_tiled2<128, 32, 640, 5>}, // 21
     {256, 32, 1024, k1_tiled2<256, 32, 1024, 4>}, // 22: one 148 KB workgroup per CU
+    {112, 32, 512, k1_tiled2<112, 32, 512>},      // 23
+    {96, 32, 512, k1_tiled2<96, 32, 512, 6>},     // 24
+    {160, 32, 512, k1_tiled2<160, 32, 512>},      // 25
+    {192, 32, 1024, k1_tiled2<192, 32, 1024>},    // 26
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
