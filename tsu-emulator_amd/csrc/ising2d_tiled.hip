@@ -395,23 +395,35 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
 
     if (!p.debug && al < RLMAX) {
         const int8_t* col = src + 16 * (long long)cq;
-        int gpar = (int)((p.row0 + Rb + al) & 1);  // colour of the even columns of row tr
-#pragma unroll 2
-        for (int tr = al; tr < TR; tr += RLMAX) {
-            const int rl = Rb + tr;
-            int srow;
-            if (p.wrap_rows) srow = rl < 0 ? rl + p.rows : (rl >= p.rows ? rl - p.rows : rl);  // rows >= TR: one wrap
-            else srow = rl < -p.ghost ? -p.ghost : (rl >= p.rows + p.ghost ? p.rows + p.ghost - 1 : rl);
-            const uint4 v = *reinterpret_cast<const uint4*>(col + (long long)srow * p.pitch);
-            // de-interleave the two colours, then +1 (0x01) -> 1, -1 (0xFF) -> 0: bit 1 of the byte, inverted
-            const uint32_t e0 = perm(v.y, v.x, 0x06040200u), e1 = perm(v.w, v.z, 0x06040200u);
-            const uint32_t o0 = perm(v.y, v.x, 0x07050301u), o1 = perm(v.w, v.z, 0x07050301u);
-            const uint64_t ev = (uint64_t)(~(e0 >> 1) & 0x01010101u) | ((uint64_t)(~(e1 >> 1) & 0x01010101u) << 32);
-            const uint64_t od = (uint64_t)(~(o0 >> 1) & 0x01010101u) | ((uint64_t)(~(o1 >> 1) & 0x01010101u) << 32);
-            const int idx = tr * NO + oct;
-            (gpar ? plane1 : plane0)[idx] = ev;
-            (gpar ? plane0 : plane1)[idx] = od;
-            if (RLMAX & 1) gpar ^= 1;
+        // four rows per step, all four 16-byte loads in flight before the first is converted: the stage is one
+        // HBM latency per step, so fewer, wider steps
+        constexpr int LB = 4;
+        for (int tr0 = al; tr0 < TR; tr0 += LB * RLMAX) {
+            uint4 v[LB];
+#pragma unroll
+            for (int b = 0; b < LB; ++b) {
+                const int tr = tr0 + b * RLMAX;
+                const int rl = Rb + (tr < TR ? tr : TR - 1);
+                int srow;
+                if (p.wrap_rows) srow = rl < 0 ? rl + p.rows : (rl >= p.rows ? rl - p.rows : rl);  // rows >= TR: one wrap
+                else srow = rl < -p.ghost ? -p.ghost : (rl >= p.rows + p.ghost ? p.rows + p.ghost - 1 : rl);
+                v[b] = *reinterpret_cast<const uint4*>(col + (long long)srow * p.pitch);
+            }
+#pragma unroll
+            for (int b = 0; b < LB; ++b) {
+                const int tr = tr0 + b * RLMAX;
+                if (tr < TR) {
+                    // de-interleave the two colours, then +1 (0x01) -> 1, -1 (0xFF) -> 0: bit 1 of the byte, inverted
+                    const uint32_t e0 = perm(v[b].y, v[b].x, 0x06040200u), e1 = perm(v[b].w, v[b].z, 0x06040200u);
+                    const uint32_t o0 = perm(v[b].y, v[b].x, 0x07050301u), o1 = perm(v[b].w, v[b].z, 0x07050301u);
+                    const uint64_t ev = (uint64_t)(~(e0 >> 1) & 0x01010101u) | ((uint64_t)(~(e1 >> 1) & 0x01010101u) << 32);
+                    const uint64_t od = (uint64_t)(~(o0 >> 1) & 0x01010101u) | ((uint64_t)(~(o1 >> 1) & 0x01010101u) << 32);
+                    const int idx = tr * NO + oct;
+                    const int gpar = (int)((p.row0 + Rb + tr) & 1);  // colour of the even columns of this row
+                    (gpar ? plane1 : plane0)[idx] = ev;
+                    (gpar ? plane0 : plane1)[idx] = od;
+                }
+            }
         }
     }
 
