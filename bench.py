@@ -165,7 +165,9 @@ def main():
             torch.cuda.synchronize()
         parallelism = "single GPU"
     else:
-        slab = SlabLattice(L, L, periodic=True, sweeps_per_exchange=k, seed=42)
+        spx = sps  # sweeps per halo exchange (one per step): 2*spx ghost rows, the slab keeps its own halo exact in between
+        slab = SlabLattice(L, L, periodic=True, sweeps_per_exchange=spx, seed=42)
+        slab.lat.set_kernel(hip.KERNEL_AUTO, k)
         slab.randomize()
         slab.set_model(1.0, 0.0, T_C, hip.MODE_PHYSICAL)
 
@@ -176,7 +178,8 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
-        parallelism = f"{world} row slabs of {L}x{L}, RCCL send/recv halo ({2 * k} rows every {k} sweeps), no collective"
+        parallelism = (f"{world} row slabs of {L}x{L}, RCCL send/recv halo ({2 * spx} rows every {spx} sweeps = "
+                       f"{spx // k} launches), no collective")
 
     for _ in range(args.warmup):
         step()

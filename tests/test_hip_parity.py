@@ -102,16 +102,18 @@ def test_ising2d_tiled_ties_and_clamps(hip):
         np.testing.assert_array_equal(lat.get_spins(), ora.ising2d_sweep(s0, True, table, 9, 99, sweep0=11))
 
 
-@pytest.mark.parametrize("nslab,ghost,k", [(2, 8, 4), (3, 16, 8), (2, 2, 1)])
-def test_ising2d_tiled_slabs(hip, nslab, ghost, k):
-    """Row slabs driven through the tiled kernel (ghost rows as the vertical halo) == whole lattice."""
+@pytest.mark.parametrize("nslab,ghost,k,spl", [(2, 8, 4, 0), (3, 16, 8, 0), (2, 2, 1, 0), (2, 32, 16, 4), (2, 40, 19, 8),
+                                                (3, 24, 12, 5)])
+def test_ising2d_tiled_slabs(hip, nslab, ghost, k, spl):
+    """Row slabs driven through the tiled kernel (ghost rows as the vertical halo) == whole lattice; with
+    k > sweeps-per-launch a slab sweeps several launches per ghost refresh, extending into its ghost rows."""
     per, cols, seed = 128, 576, 31
     rows = per * nslab
     table = ora.ising2d_thresholds(1.0, 0.0, 2.269185, 0)
     full = ora.ising2d_randomize(rows, cols, seed)
     slabs = [hip.Lattice(per, cols, True, total_rows=rows, row0=i * per, ghost=ghost) for i in range(nslab)]
     for i, s in enumerate(slabs):
-        s.set_kernel(hip.KERNEL_TILED, 0)
+        s.set_kernel(hip.KERNEL_TILED, spl)
         s.set_spins(full[i * per:(i + 1) * per])
         s.set_thresholds(table)
     want = full

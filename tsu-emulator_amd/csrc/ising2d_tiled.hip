@@ -22,6 +22,9 @@ struct TiledParams {
     int8_t* dst;        // owned row 0 of the destination buffer
     long long pitch;
     int rows, nchunks;           // owned rows; cols / 16
+    int tile_h;                  // tile height of this launch (even; the template H is the default and the LDS budget)
+    int r_begin, r_end;          // rows this launch computes: [0, rows) or, for a slab that will sweep again before its
+                                 // next ghost refresh, [-ext, rows + ext) so that its own halo stays exact
     long long row0, total_rows;  // global row of owned row 0; global lattice height
     int wrap_rows, ghost;        // source rows wrap inside the buffer, or come from `ghost` ghost rows
     int k;                       // sweeps in this launch
@@ -131,8 +134,9 @@ static __device__ __forceinline__ void sweep_rows(const RowsCtx& c, int tid) {
     }
 }
 
-template <int H, int WO, int THREADS>
+template <int HT, int WO, int THREADS>
 __global__ __launch_bounds__(THREADS) void k1_tiled(TiledParams p) {
+    const int H = p.tile_h;
     constexpr int NO = WO + 2;  // octets per tile row including one halo octet each side
     extern __shared__ uint64_t lds[];
     const int k = p.k;
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(THREADS) void k1_tiled(TiledParams p) {
 
     const int tx = blockIdx.x % p.tiles_x, ty = p.ty_first + (blockIdx.x / p.tiles_x) * p.ty_stride;
     const int q0 = tx * WO;      // first interior chunk (16 columns each)
-    const int r0 = ty * H;       // first interior owned row
+    const int r0 = p.r_begin + ty * H;  // first interior row of this tile
     const int Rb = r0 - 2 * k;   // owned-row index of tile row 0
 
     // ---------------------------------------------------------------- stage the tile: HBM -> 2 colour planes
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(THREADS) void k1_tiled(TiledParams p) {
     for (int idx = tid; idx < (p.debug >= 2 ? 0 : H * WO); idx += THREADS) {
         int hr = idx / WO, oc = idx - hr * WO + 1;
         int rl = r0 + hr, cq = q0 + oc - 1;
-        if (rl >= p.rows || cq >= p.nchunks) continue;
+        if (rl >= p.r_end || cq >= p.nchunks) continue;
         int li = (2 * k + hr) * NO + oc;
         int gpar = (int)((p.row0 + rl) & 1);
         uint64_t ev = (gpar ? plane1 : plane0)[li], od = (gpar ? plane0 : plane1)[li];
@@ -364,12 +368,13 @@ static __device__ __forceinline__ void sweep_pairs(const Rows2Ctx& c, const Phil
 }
 
 // one tile: HBM -> LDS planes, 2k half-sweeps, interior -> HBM (the other buffer)
-template <int H, int WO, int THREADS>
+template <int HT, int WO, int THREADS>
 static __device__ __forceinline__ void tile_body(const TiledParams& p, const int8_t* __restrict__ src, int8_t* __restrict__ dst,
                                                  const int k, const uint32_t sweep0, const int tx, const int ty, uint64_t* lds,
                                                  const PhiloxKeys& K) {
     constexpr int NO = WO + 2;
     constexpr int RLMAX = THREADS / NO;
+    const int H = p.tile_h;
     const int TR = H + 4 * k;
     // Row lanes: threads [0, RL*NO) sweep (thread = one octet column x every RL-th row pair); all threads load and
     // store.  A half-sweep costs ceil(npairs / RL) iterations per thread whatever the trapezoid removes, so RL is
@@ -383,7 +388,7 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
     const int tid = threadIdx.x;
     if (tid < 5) s_thr[tid] = p.thr[tid];
 
-    const int q0 = tx * WO, r0 = ty * H, Rb = r0 - 2 * k;
+    const int q0 = tx * WO, r0 = p.r_begin + ty * H, Rb = r0 - 2 * k;
 
     // a thread owns one octet column (al = row lane, oct = column) in all three phases: no div/mod in any loop
     const int al = tid / NO, oct = tid - al * NO;
@@ -473,7 +478,7 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
 #pragma unroll 2
         for (int hr = al; hr < H; hr += RLMAX) {
             const int rl = r0 + hr;
-            if (rl < p.rows) {
+            if (rl < p.r_end) {
                 const int li = (2 * k + hr) * NO + oct;
                 const uint64_t ev = (gpar ? plane1 : plane0)[li], od = (gpar ? plane0 : plane1)[li];
                 // up flag -> spin byte: 1 -> 0x01, 0 -> 0xFF
@@ -661,11 +666,12 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
     int kmax = L->sweeps_per_launch > 0 ? L->sweeps_per_launch : ((long long)L->rows * L->cols <= 4096ll * 4096ll ? 8 : 5);
     if (kmax > KMAX) kmax = KMAX;
     if (!L->wrap_rows) {
-        // ghost rows are only fresh for the first launch: all requested sweeps go into one launch
-        TSU_REQUIRE(ctx, n_sweeps <= KMAX && 2 * n_sweeps <= L->ghost,
-                    "ising2d_sweep (tiled, slab): %d sweeps per ghost refresh exceed min(%d, ghost/2 = %d)", n_sweeps, KMAX,
-                    L->ghost / 2);
-        kmax = n_sweeps;
+        // A slab may sweep ghost/2 times between two ghost refreshes.  When that takes several launches, every launch
+        // but the last also computes the ghost rows the following launches will read (2 rows per remaining sweep on
+        // each side, from input that is still exact there), instead of waiting for the neighbours.
+        TSU_REQUIRE(ctx, 2 * n_sweeps <= L->ghost, "ising2d_sweep (tiled, slab): %d sweeps per ghost refresh exceed ghost/2 = %d",
+                    n_sweeps, L->ghost / 2);
+        TSU_REQUIRE(ctx, part == TSU_PART_ALL || n_sweeps <= kmax, "ising2d_sweep_part: split sweeps take at most %d sweeps", kmax);
     }
     TiledParams p;
     p.pitch = (long long)L->pitch;
@@ -684,6 +690,9 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
         }
         p.debug = dbg;
     }
+    p.r_begin = 0;
+    p.r_end = L->rows;
+    p.tile_h = TILE_H;
     int tiles_y = (L->rows + TILE_H - 1) / TILE_H;
     p.k0 = (uint32_t)seed;
     p.k1 = (uint32_t)(seed >> 32);
@@ -777,6 +786,23 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
         p.dst = L->alloc[L->cur ^ 1] + (size_t)L->ghost * L->pitch;
         int TR = TILE_H + 4 * k;
         size_t lds_bytes = ((size_t)2 * TR * TILE_NO + TILE_NO + 2 + 5) * sizeof(uint64_t);
+        if (!L->wrap_rows && part == TSU_PART_ALL) {
+            const int ext = 2 * (n_sweeps - done - k);  // rows of ghost the remaining sweeps of this refresh period need
+            p.r_begin = -ext;
+            p.r_end = L->rows + ext;
+            // keep the number of tile rows (an extra, nearly empty tile row can cost a whole extra round of tiles):
+            // stretch the tiles instead, if the taller tile still fits the LDS share this variant runs with
+            const int base_ty = (L->rows + TILE_H - 1) / TILE_H;
+            int th = (p.r_end - p.r_begin + base_ty - 1) / base_ty;
+            th += th & 1;
+            const size_t lds_share = (tv.threads >= 1024 ? 160u : 80u) * 1024u;
+            const size_t need = ((size_t)2 * (th + 4 * k) * TILE_NO + TILE_NO + 2 + 5) * sizeof(uint64_t);
+            if (need > lds_share || th < TILE_H) th = TILE_H;
+            p.tile_h = th;
+            tiles_y = (p.r_end - p.r_begin + th - 1) / th;
+            TR = th + 4 * k;
+            lds_bytes = ((size_t)2 * TR * TILE_NO + TILE_NO + 2 + 5) * sizeof(uint64_t);
+        }
         // tile rows 0 and tiles_y-1 read ghost rows (2k <= H); the others only read owned rows
         int n_ty = tiles_y;
         p.ty_first = 0;

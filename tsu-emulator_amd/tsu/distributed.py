@@ -3,16 +3,19 @@
 The reference has no parallelism of any kind; this is new design for the path
 ``IsingGrid`` / ``IsingModel2D.gibbs_update`` at sizes one GPU cannot hold or should not sweep alone.
 
-Rank r owns rows [r*R, (r+1)*R) of a (P*R) x cols lattice plus ``ghost = 2k`` ghost rows on each side.  Every k
-sweeps the ranks exchange their 2k boundary rows with the rank above and below (``torch.distributed``
-point-to-point, i.e. RCCL send/recv over xGMI with the ``nccl`` backend): one exchange per k sweeps instead of
-two per sweep, because each half-sweep consumes one ghost row.  Philox counters use
+Rank r owns rows [r*R, (r+1)*R) of a (P*R) x cols lattice plus ``ghost = 2S`` ghost rows on each side.  Every S
+sweeps (``sweeps_per_exchange``) the ranks exchange their 2S boundary rows with the rank above and below
+(``torch.distributed`` point-to-point, i.e. RCCL send/recv over xGMI with the ``nccl`` backend): one exchange per
+S sweeps instead of two per sweep, because each half-sweep consumes one ghost row.  S may span several kernel
+launches: between two exchanges a slab keeps its own halo exact by also sweeping the ghost rows the later launches
+will read (2 rows per remaining sweep; < 1 % extra work), so the message latency is paid once per S sweeps.  Philox counters use
 GLOBAL (row, column, sweep) coordinates, so the trajectory is bit-identical for every P (tested).
 
-Overlap: the tile rows that do not touch ghost rows (all but the first and last 64 rows of the slab) are swept
-on the compute stream while the ghost rows travel on a second stream; the two boundary tile rows follow once the
-exchange has landed (``tsu_ising2d_sweep_part``).  There is no collective on the sweep path; observables need
-one all-reduce of two int64.
+Optional overlap (``overlap=True``, S <= 8): the tile rows that do not touch ghost rows are swept on the compute
+stream while the ghost rows travel on a second stream; the two boundary tile rows follow once the exchange has
+landed (``tsu_ising2d_sweep_part``).  It only pays when a slab has several tiles per CU: at 4096 x 4096 per GPU
+every launch lasts one tile-time however few tiles it has, so the default is the deep-ghost schedule above.
+There is no collective on the sweep path; observables need one all-reduce of two int64.
 """
 from typing import Optional
 
@@ -38,7 +41,7 @@ class SlabLattice:
     """
 
     def __init__(self, rows_per_rank: int, cols: int, periodic: bool = True, sweeps_per_exchange: int = 4,
-                 seed: int = 0, group=None, engine=None, overlap: bool = True, device: Optional[int] = None):
+                 seed: int = 0, group=None, engine=None, overlap: bool = False, device: Optional[int] = None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
