@@ -135,11 +135,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # one rank per GPU; BENCH_BACKEND=gloo lets several ranks share a GPU (rehearsal of the N > 1 path on a 1-GPU box)
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
 
     from tsu import _hip as hip
     from tsu.distributed import SlabLattice
@@ -192,7 +198,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed, ev_ms], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed, ev_ms], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, ev_ms = float(t[0]), float(t[1])
 
@@ -223,6 +229,7 @@ def main():
             "value": value, "unit": "spin-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int8", "data": "synthetic (Philox i.i.d. +-1 start, seed 42)",
+            "backend": backend if world > 1 else None,
             "config": {"workload": f"IsingModel2D {L}x{L} per GPU at T_c=2.269185, J=1, h=0, periodic, checkerboard Gibbs sweep "
                                    "(BASELINE.json configs[1])", "L": L, "lattice_rows": L * world, "lattice_cols": L,
                        "sweeps_per_step": sps, "sweeps_per_launch": k, "kernel": "k1_tiled2 (LDS halo tiles, row-pair inner loop)",
