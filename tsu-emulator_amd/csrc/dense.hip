@@ -39,6 +39,13 @@ struct tsu_dense {
     double* uniforms;
     size_t order_cap, uni_cap;
     double* d_energy;
+    // superblock fixed-point path
+    int8_t* delta[2];   // ping-pong flip vectors of the current superblock
+    double* logit;      // T * logit(u) per site of the current superblock... stored as logit(u)
+    int* sb_sync;       // [0 .. SB_MAX_IT): changes per iteration, [SB_MAX_IT]: converged flag, per superblock
+    int8_t* backup;     // state at the start of the call (re-run on the exact path if a superblock did not converge)
+    int sb_cap;         // superblocks allocated in sb_sync
+    int sb_budget;      // iteration launches per superblock: slowest fixed point of the last call + 8 (16 .. SB_MAX_IT)
 };
 
 template <typename TJ>
@@ -260,6 +267,168 @@ __global__ __launch_bounds__(256) void k2_energy(const double* __restrict__ f, c
     if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
 }
 
+// ================================================================== superblock fixed-point resolve
+// The sequential sweep is the unique solution of a triangular system: delta_i = dec_i(f_i + sum_{j<i} J_ij delta_j).
+// For a superblock of S consecutive positions that system is solved by fixed-point iteration with ALL sites of the
+// block updated in parallel: iteration m is one row-parallel triangular matvec over the S x S sub-block (which
+// stays in L2) plus one decision per site.  Site i is exact from iteration i on, so the iteration reaches the
+// sequential result; in practice the intra-block corrections are small against the decision gaps and it converges
+// in about ten iterations.  A launch finds "no site changed in the previous iteration" and returns at once, so a
+// fixed launch budget costs little; if the budget is exhausted without convergence the whole call is re-run on the
+// block-by-block path (k2_block) from a backup of the state.  Natural visiting order only.
+#define SB_SIZE 2048
+#define SB_MAX_IT 32  // slots per superblock; the launch budget adapts below this
+
+template <typename TJ>
+__global__ __launch_bounds__(256) void k2_sb_iter(const TJ* __restrict__ J, const int8_t* __restrict__ s,
+                                                 const double* __restrict__ f, const double* __restrict__ uniforms,
+                                                 const int8_t* __restrict__ din, int8_t* __restrict__ dout,
+                                                 double* __restrict__ logit, int* __restrict__ sync, int m, int n, int p0,
+                                                 int cnt, double T, uint32_t sweep, uint32_t tag, uint32_t k0, uint32_t k1) {
+    if (m > 0 && sync[m - 1] == 0) return;  // the previous iteration changed nothing: delta is the fixed point
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= cnt) return;
+    const int site = p0 + wave;
+    double c = 0.0;
+    if (m > 0) {  // iteration 0 starts from delta = 0
+        const TJ* row = J + (size_t)site * n + p0;
+        for (int j = lane; j < wave; j += 64) {
+            const int dj = din[j];
+            if (dj) c += (double)dj * (double)row[j];
+        }
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    }
+    if (lane == 0) {
+        double lg;
+        double u = 0.0;
+        if (m == 0) {
+            u = uniforms ? uniforms[site] : dense_uniform((uint32_t)site, sweep, tag, k0, k1);
+            lg = log(u) - log1p(-u);
+            logit[wave] = lg;
+        } else {
+            lg = logit[wave];
+        }
+        const double F = f[site] + c;
+        const double xa = F * (1.0 / T);
+        int cand;
+        if (fabs(fabs(xa) - 20.0) < 1e-9 || fabs(xa - lg) <= 1e-9 * (1.0 + fabs(lg))) {
+            if (m > 0) u = uniforms ? uniforms[site] : dense_uniform((uint32_t)site, sweep, tag, k0, k1);
+            cand = (u < sigmoid_clamped(F / T)) ? 1 : 0;  // the reference's own expression decides close calls
+        } else if (xa > 20.0) cand = 1;
+        else if (xa < -20.0) cand = 0;
+        else cand = xa > lg ? 1 : 0;
+        const int8_t dn = (int8_t)(cand - (int)s[site]);
+        const int8_t dp = m > 0 ? din[wave] : (int8_t)0;
+        dout[wave] = dn;
+        if (dn != dp) atomicAdd(&sync[m], 1);
+    }
+}
+
+// commit the superblock (new bits into the next-state array, convergence flag) and add its flips to the fields of
+// every later site: one wave per later row, reading the S contiguous entries J[row][p0 .. p0+cnt)
+template <typename TJ>
+__global__ __launch_bounds__(256) void k2_sb_finish(const TJ* __restrict__ J, const int8_t* __restrict__ s,
+                                                   int8_t* __restrict__ s_new, double* __restrict__ f,
+                                                   const int8_t* __restrict__ d0, const int8_t* __restrict__ d1,
+                                                   int* __restrict__ sync, int n, int p0, int cnt, int budget) {
+    const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    // the fixed point sits in the buffer iteration mc wrote, mc = first iteration that changed nothing (later launches
+    // returned without writing); without convergence take the last buffer written (the host re-runs the call anyway)
+    int mc = budget - 1;
+    for (int m = budget - 1; m >= 0; --m)
+        if (sync[m] == 0) mc = m;
+    const int8_t* __restrict__ dfinal = (mc & 1) ? d1 : d0;
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) s_new[p0 + i] = (int8_t)(s[p0 + i] + dfinal[i]);
+        if (threadIdx.x == 0) {
+            int ok = 0;
+            for (int m = 0; m < budget; ++m) ok |= (sync[m] == 0);
+            sync[SB_MAX_IT] = ok;
+        }
+    }
+    const int row = p0 + cnt + gw;
+    if (row >= n) return;
+    const TJ* jr = J + (size_t)row * n + p0;
+    double c = 0.0;
+    for (int j = lane; j < cnt; j += 64) {
+        const int dj = dfinal[j];
+        if (dj) c += (double)dj * (double)jr[j];
+    }
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if (lane == 0) f[row] += c;
+}
+
+template <typename TJ>
+static int dense_sweep_superblocks(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint32_t sweep0, uint32_t replica,
+                                   bool have_uni, int* converged) {
+    if (d->sb_budget < 16) d->sb_budget = 20;
+    const int budget = d->sb_budget;
+    tsu_ctx* ctx = d->ctx;
+    const TJ* J = (const TJ*)d->J;
+    const int n = d->n;
+    const uint32_t tag = TSU_TAG_DENSE | (replica << 8);
+    const int nsb = (n + SB_SIZE - 1) / SB_SIZE;
+    const size_t sync_ints = (size_t)nsb * n_sweeps * (SB_MAX_IT + 1);
+    if (!d->delta[0]) {
+        TSU_HIP_TRY(ctx, hipMalloc(&d->delta[0], SB_SIZE));
+        TSU_HIP_TRY(ctx, hipMalloc(&d->delta[1], SB_SIZE));
+        TSU_HIP_TRY(ctx, hipMalloc(&d->logit, SB_SIZE * sizeof(double)));
+        TSU_HIP_TRY(ctx, hipMalloc(&d->backup, (size_t)n));
+    }
+    if ((size_t)d->sb_cap < sync_ints) {
+        if (d->sb_sync) (void)hipFree(d->sb_sync);
+        d->sb_sync = nullptr;
+        d->sb_cap = 0;
+        TSU_HIP_TRY(ctx, hipMalloc(&d->sb_sync, sync_ints * sizeof(int)));
+        d->sb_cap = (int)sync_ints;
+    }
+    TSU_HIP_TRY(ctx, hipMemsetAsync(d->sb_sync, 0, sync_ints * sizeof(int), ctx->stream));
+    TSU_HIP_TRY(ctx, hipMemcpyAsync(d->backup, d->state, (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+    const unsigned mv_grid = (unsigned)(((size_t)n * 64 + 255) / 256);
+    int* sync = d->sb_sync;
+    for (int s = 0; s < n_sweeps; ++s) {
+        TSU_HIP_TRY(ctx, hipMemcpyAsync(d->state2, d->state, (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+        k2_matvec<TJ><<<mv_grid, 256, 0, ctx->stream>>>(J, d->state, d->bias, d->field, n);
+        const double* uni = have_uni ? d->uniforms + (size_t)s * n : nullptr;
+        for (int p0 = 0; p0 < n; p0 += SB_SIZE, sync += SB_MAX_IT + 1) {
+            const int cnt = n - p0 < SB_SIZE ? n - p0 : SB_SIZE;
+            const unsigned it_grid = (unsigned)((cnt * 64 + 255) / 256);
+            for (int m = 0; m < budget; ++m)
+                k2_sb_iter<TJ><<<it_grid, 256, 0, ctx->stream>>>(J, d->state, d->field, uni, d->delta[(m + 1) & 1], d->delta[m & 1],
+                                                                 d->logit, sync, m, n, p0, cnt, T, sweep0 + (uint32_t)s, tag,
+                                                                 (uint32_t)seed, (uint32_t)(seed >> 32));
+            const int later = n - (p0 + cnt);
+            const unsigned fin_grid = (unsigned)(((size_t)(later > 0 ? later : 1) * 64 + 255) / 256);
+            k2_sb_finish<TJ><<<fin_grid, 256, 0, ctx->stream>>>(J, d->state, d->state2, d->field, d->delta[0], d->delta[1], sync, n, p0,
+                                                               cnt, budget);
+        }
+        int8_t* t = d->state;
+        d->state = d->state2;
+        d->state2 = t;
+    }
+    TSU_HIP_TRY(ctx, hipGetLastError());
+    // one synchronisation per call: did every superblock reach its fixed point within the launch budget?
+    std::vector<int> h(sync_ints);
+    TSU_HIP_TRY(ctx, hipMemcpyAsync(h.data(), d->sb_sync, sync_ints * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *converged = 1;
+    int worst = 0;
+    for (size_t b = 0; b < (size_t)nsb * n_sweeps; ++b) {
+        if (!h[b * (SB_MAX_IT + 1) + SB_MAX_IT]) *converged = 0;
+        int mc = budget;
+        for (int m = budget - 1; m >= 0; --m)
+            if (h[b * (SB_MAX_IT + 1) + m] == 0) mc = m;
+        if (mc > worst) worst = mc;
+    }
+    // adapt the launch budget to this system (temperature, coupling strength): slowest fixed point + margin
+    // (an unused launch exits at once and costs ~3 us; a failed attempt costs the whole call again)
+    d->sb_budget = *converged ? (worst + 8 < 16 ? 16 : (worst + 8 > SB_MAX_IT ? SB_MAX_IT : worst + 8)) : SB_MAX_IT;
+    if (getenv("TSU_K2_VERBOSE"))
+        fprintf(stderr, "[tsu] dense superblocks: n=%d, %d superblocks x %d sweeps, slowest fixed point after %d iterations (budget %d, next %d)\n",
+                n, nsb, n_sweeps, worst, budget, d->sb_budget);
+    return TSU_OK;
+}
+
 template <typename TJ>
 static int dense_sweep_impl(tsu_dense* d, double T, int n_sweeps, bool have_order, uint64_t seed, uint32_t sweep0,
                             uint32_t replica, bool have_uni) {
@@ -371,6 +540,11 @@ int tsu_dense_destroy(tsu_dense* d) {
     if (d->order) (void)hipFree(d->order);
     if (d->uniforms) (void)hipFree(d->uniforms);
     if (d->d_energy) (void)hipFree(d->d_energy);
+    if (d->delta[0]) (void)hipFree(d->delta[0]);
+    if (d->delta[1]) (void)hipFree(d->delta[1]);
+    if (d->logit) (void)hipFree(d->logit);
+    if (d->sb_sync) (void)hipFree(d->sb_sync);
+    if (d->backup) (void)hipFree(d->backup);
     delete d;
     return TSU_OK;
 }
@@ -432,6 +606,29 @@ int tsu_dense_sweep(tsu_dense* d, double T, int n_sweeps, const int64_t* order, 
         TSU_HIP_TRY(ctx, hipMemcpyAsync(d->uniforms, replay_uniforms, cnt * 8, hipMemcpyHostToDevice, ctx->stream));
     }
     if (order || replay_uniforms) TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host buffers are the caller's
+    static int use_sb = -1;
+    if (use_sb < 0) {
+        const char* e = getenv("TSU_K2_SUPERBLOCK");
+        use_sb = e ? atoi(e) : 1;
+    }
+    if (use_sb && !order && d->n >= 2 * DB) {
+        int ok = 0;
+        int rc = d->dtype == TSU_DTYPE_F64
+                     ? dense_sweep_superblocks<double>(d, T, n_sweeps, seed, sweep0, replica, replay_uniforms != nullptr, &ok)
+                     : dense_sweep_superblocks<float>(d, T, n_sweeps, seed, sweep0, replica, replay_uniforms != nullptr, &ok);
+        if (rc != TSU_OK) return rc;
+        if (!ok) {
+            // a superblock ran out of iteration launches: restore the state and retry once with the full budget
+            TSU_HIP_TRY(ctx, hipMemcpyAsync(d->state, d->backup, (size_t)d->n, hipMemcpyDeviceToDevice, ctx->stream));
+            rc = d->dtype == TSU_DTYPE_F64
+                     ? dense_sweep_superblocks<double>(d, T, n_sweeps, seed, sweep0, replica, replay_uniforms != nullptr, &ok)
+                     : dense_sweep_superblocks<float>(d, T, n_sweeps, seed, sweep0, replica, replay_uniforms != nullptr, &ok);
+            if (rc != TSU_OK) return rc;
+        }
+        if (ok) return TSU_OK;
+        // still not converged within SB_MAX_IT iterations: redo the call on the exact block-by-block path
+        TSU_HIP_TRY(ctx, hipMemcpyAsync(d->state, d->backup, (size_t)d->n, hipMemcpyDeviceToDevice, ctx->stream));
+    }
     if (d->dtype == TSU_DTYPE_F64)
         return dense_sweep_impl<double>(d, T, n_sweeps, order != nullptr, seed, sweep0, replica, replay_uniforms != nullptr);
     return dense_sweep_impl<float>(d, T, n_sweeps, order != nullptr, seed, sweep0, replica, replay_uniforms != nullptr);
