@@ -100,18 +100,19 @@ def time_langevin(hip, ctx):
     return out
 
 
-def time_dense(hip, ctx, n=4096):
+def time_dense(hip, ctx, n=16384):
+    """BASELINE configs[2]: dense Gibbs, N=16384 fp32 couplings (1 GiB of J), natural visiting order."""
     rng = np.random.default_rng(42)
     G = rng.standard_normal((n, n)).astype(np.float32)
     J = ((G + G.T) / 2 / np.sqrt(n)).astype(np.float32)
     np.fill_diagonal(J, 0.0)
     d = hip.DenseSystem(J, None, hip.DTYPE_F32, ctx=ctx)
     d.set_state(rng.integers(0, 2, size=n).astype(np.int8))
-    d.sweep(1.0, 1, seed=1, sweep0=0)
+    d.sweep(1.0, 2, seed=1, sweep0=0)
     ctx.synchronize()
     ctx.timer_begin()
-    d.sweep(1.0, 4, seed=1, sweep0=1)
-    ms = ctx.timer_end() / 4
+    d.sweep(1.0, 8, seed=1, sweep0=2)
+    ms = ctx.timer_end() / 8
     d.close()
     return {"N": n, "dtype": "f32", "ms_per_sweep": ms, "spin_updates_per_s": n / (ms * 1e-3),
             "J_stream_GBps": n * n * 4 / (ms * 1e-3) / 1e9}
