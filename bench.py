@@ -61,6 +61,39 @@ def cpu_reference_order(budget_s=4.0):
             "sample": f"reference-order per-site NumPy loop, IsingGrid 32x32 dense J, T=2.5, {n} sweeps in {dt:.1f} s"}
 
 
+def cpu_numpy_checkerboard(L, budget_s=3.0):
+    """a vectorised NumPy checkerboard heat-bath sweep (np.random uniforms) on one core --
+    NOT the reference's algorithm (which is a per-site Python loop), just what NumPy alone reaches on this host."""
+    rng = np.random.RandomState(42)
+    s = (2 * rng.randint(0, 2, size=(L, L)) - 1).astype(np.int8)
+    ii, jj = np.indices((L, L), sparse=True)
+    masks = [((ii + jj) & 1) == c for c in (0, 1)]
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        for m in masks:
+            nb = np.roll(s, 1, 0) + np.roll(s, -1, 0) + np.roll(s, 1, 1) + np.roll(s, -1, 1)
+            p = 1.0 / (1.0 + np.exp(-2.0 * nb / T_C))
+            s = np.where(m, np.where(rng.random_sample((L, L)) < p, 1, -1), s).astype(np.int8)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": L * L * n / dt, "unit": "spin-updates/s", "cores": 1, "kind": "numpy-vectorised, not the reference",
+            "sample": f"L={L}, T_c, {n} sweeps in {dt:.1f} s"}
+
+
+def cpu_numpy_langevin(budget_s=2.0):
+    """the reference's _langevin_step arithmetic (x - g dt/gamma + sqrt(2 T dt/gamma) randn, f64)
+    with the analytic gradient of E = sum x^2, d = 2^20, one core."""
+    d = 1 << 20
+    x = np.zeros(d)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        x = x - (2.0 * x) * 0.01 + np.sqrt(2.0 * 0.01) * np.random.randn(d)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": d * n / dt, "unit": "element-steps/s", "cores": 1, "kind": "numpy f64",
+            "sample": f"d=2^20, {n} steps in {dt:.1f} s, variance {x.var():.3f}"}
+
+
 def time_lattice(hip, ctx, L, k, sweeps, reps=3):
     lat = hip.Lattice(L, L, True, ctx=ctx)
     lat.randomize(42)
@@ -124,7 +157,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--L", type=int, default=4096)
-    ap.add_argument("--sweeps-per-step", type=int, default=0, help="0 = auto: the multiple of sweeps-per-launch nearest 64")
+    ap.add_argument("--sweeps-per-step", type=int, default=0, help="0 = auto: 4 halo-exchange periods (256 sweeps at k=8)")
+    ap.add_argument("--sweeps-per-exchange", type=int, default=0, help="N>1: 0 = auto, the multiple of sweeps-per-launch nearest 64")
+    ap.add_argument("--ramp-steps", type=int, default=20, help="untimed steps before the W warmup steps (GPU clock ramp, ~30 ms)")
     ap.add_argument("--sweeps-per-launch", type=int, default=0, help="0 = auto: 8 up to 4096^2 per GPU, 5 above")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
@@ -154,7 +189,10 @@ def main():
     hip.Context._default = ctx
     L = args.L
     k = args.sweeps_per_launch or (8 if L * L <= 4096 * 4096 else 5)
-    sps = args.sweeps_per_step or k * round(64 / k)
+    spx = args.sweeps_per_exchange or k * round(64 / k)   # sweeps between two halo exchanges (2*spx ghost rows)
+    sps = args.sweeps_per_step or 4 * spx                  # one step: ~1.6 ms at 4096^2
+    if world > 1 and sps % spx:
+        raise SystemExit("--sweeps-per-step must be a multiple of --sweeps-per-exchange")
 
     if world == 1:
         lat = hip.Lattice(L, L, True, ctx=ctx)
@@ -172,7 +210,7 @@ def main():
             torch.cuda.synchronize()
         parallelism = "single GPU"
     else:
-        spx = sps  # sweeps per halo exchange (one per step): 2*spx ghost rows, the slab keeps its own halo exact in between
+        # one halo exchange per spx sweeps; the slab keeps its own halo exact in between (deep ghost rows)
         slab = SlabLattice(L, L, periodic=True, sweeps_per_exchange=spx, seed=42)
         slab.lat.set_kernel(hip.KERNEL_AUTO, k)
         slab.randomize()
@@ -188,6 +226,10 @@ def main():
         parallelism = (f"{world} row slabs of {L}x{L}, RCCL send/recv halo ({2 * spx} rows every {spx} sweeps = "
                        f"{spx // k} launches), no collective")
 
+    # The first ~10 ms of work after idle run ~6 % slower (clock ramp): spend them before the warmup steps.
+    # (a fixed count, so that every rank issues the same halo exchanges)
+    for _ in range(args.ramp_steps):
+        step()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -233,7 +275,8 @@ def main():
             "backend": backend if world > 1 else None,
             "config": {"workload": f"IsingModel2D {L}x{L} per GPU at T_c=2.269185, J=1, h=0, periodic, checkerboard Gibbs sweep "
                                    "(BASELINE.json configs[1])", "L": L, "lattice_rows": L * world, "lattice_cols": L,
-                       "sweeps_per_step": sps, "sweeps_per_launch": k, "kernel": "k1_tiled2 (LDS halo tiles, row-pair inner loop)",
+                       "sweeps_per_step": sps, "sweeps_per_launch": k, "sweeps_per_exchange": spx if world > 1 else None,
+                       "clock_ramp_steps_before_warmup": args.ramp_steps, "kernel": "k1_tiled2 (LDS halo tiles, row-pair inner loop)",
                        "bias_mode": "physical", "parallelism": parallelism, "launches": n_launches,
                        "avg_launch_us": avg_launch_ms * 1e3, "algorithmic_bytes_per_launch": alg_bytes_per_launch},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -247,6 +290,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(L)
             out["cpu_reference_order"] = cpu_reference_order()
+            out["cpu_numpy_checkerboard"] = cpu_numpy_checkerboard(min(L, 2048))
+            out["cpu_numpy_langevin"] = cpu_numpy_langevin()
         if not args.no_extra and world == 1:
             lat.close()
             extra = {}

@@ -126,7 +126,9 @@ int tsu_ising2d_observables(tsu_ising2d* lat, int64_t* sum_s, int64_t* sum_bonds
 /* device address of local row r in [-ghost, rows+ghost) and the row pitch in bytes, for halo exchange
  * by the host (RCCL send/recv through torch.distributed on the same stream) */
 int tsu_ising2d_row_ptr(tsu_ising2d* lat, int local_row, void** device_ptr, size_t* pitch_bytes);
-/* milliseconds of the most recent tsu_ising2d_sweep measured with HIP events (synchronises) */
+/* Per-call timing (off by default: two event records per call cost ~2 % at 8 launches per call).  With timing on,
+ * tsu_ising2d_last_sweep_ms returns the milliseconds of the most recent tsu_ising2d_sweep (HIP events; synchronises). */
+int tsu_ising2d_set_timing(tsu_ising2d* lat, int enable);
 int tsu_ising2d_last_sweep_ms(tsu_ising2d* lat, float* ms);
 
 /* ------------------------------------------------------------------ dense coupling matrix (K2)

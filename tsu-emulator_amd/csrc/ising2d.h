@@ -18,7 +18,7 @@ struct tsu_ising2d {
     int kernel, sweeps_per_launch;
     int64_t* d_obs;      // 2 x int64 accumulators
     hipEvent_t ev0, ev1;
-    int timed;
+    int timed, timing;
     int* d_sync;         // persistent kernel: [0] ticket, [1..] per-tile generation counters
     size_t sync_cap;     // ints allocated in d_sync
     int* h_err;          // host-mapped flag the persistent kernel sets if a bounded wait expires

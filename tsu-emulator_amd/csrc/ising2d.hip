@@ -341,6 +341,7 @@ int tsu_ising2d_create_slab(tsu_ctx* ctx, int64_t total_rows, int cols, int peri
     L->sweeps_per_launch = 0;
     L->d_obs = nullptr;
     L->timed = 0;
+    L->timing = 0;
     L->d_sync = nullptr;
     L->sync_cap = 0;
     L->h_err = nullptr;
@@ -486,7 +487,7 @@ int tsu_ising2d_sweep_part(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_t
     TSU_REQUIRE(ctx, L->ghost == 0 || 2 * n_sweeps <= L->ghost,
                 "ising2d_sweep: %d sweeps need %d ghost rows, slab has %d", n_sweeps, 2 * n_sweeps, L->ghost);
     if (n_sweeps == 0) return TSU_OK;
-    TSU_HIP_TRY(ctx, hipEventRecord(L->ev0, ctx->stream));
+    if (L->timing) TSU_HIP_TRY(ctx, hipEventRecord(L->ev0, ctx->stream));
     int use_tiled = (L->kernel == TSU_KERNEL_TILED) || (L->kernel == TSU_KERNEL_AUTO && tsu_ising2d_tiled_supported(L));
     if (part != TSU_PART_ALL && !(use_tiled && tsu_ising2d_tiled_part_supported(L)))
         return tsu_fail(ctx, TSU_E_UNSUPPORTED, "ising2d_sweep_part: split sweeps need a slab on the tiled kernel with rows %% 64 == 0");
@@ -517,14 +518,23 @@ int tsu_ising2d_sweep_part(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_t
             }
         TSU_HIP_TRY(ctx, hipGetLastError());
     }
-    TSU_HIP_TRY(ctx, hipEventRecord(L->ev1, ctx->stream));
-    L->timed = 1;
+    if (L->timing) {
+        TSU_HIP_TRY(ctx, hipEventRecord(L->ev1, ctx->stream));
+        L->timed = 1;
+    }
+    return TSU_OK;
+}
+
+int tsu_ising2d_set_timing(tsu_ising2d* L, int enable) {
+    if (!L) return TSU_E_INVALID;
+    L->timing = enable != 0;
+    L->timed = 0;
     return TSU_OK;
 }
 
 int tsu_ising2d_last_sweep_ms(tsu_ising2d* L, float* ms) {
     if (!L || !ms) return TSU_E_INVALID;
-    TSU_REQUIRE(L->ctx, L->timed, "ising2d_last_sweep_ms: no sweep has been timed yet");
+    TSU_REQUIRE(L->ctx, L->timed, "ising2d_last_sweep_ms: no sweep has been timed (tsu_ising2d_set_timing(lat, 1), then sweep)");
     TSU_HIP_TRY(L->ctx, hipEventSynchronize(L->ev1));
     TSU_HIP_TRY(L->ctx, hipEventElapsedTime(ms, L->ev0, L->ev1));
     return check_persist_error(L);

@@ -64,6 +64,7 @@ SIGNATURES = {
     "tsu_ising2d_sweep_part": (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]),
     "tsu_ising2d_observables": (C.c_int, [_vp, _i64p, _i64p]),
     "tsu_ising2d_row_ptr": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "tsu_ising2d_set_timing": (C.c_int, [_vp, C.c_int]),
     "tsu_ising2d_last_sweep_ms": (C.c_int, [_vp, _f32p]),
     "tsu_dense_create": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _f64p, C.POINTER(_vp)]),
     "tsu_dense_destroy": (C.c_int, [_vp]),
@@ -254,6 +255,9 @@ class Lattice:
         p, pitch = _vp(), C.c_size_t(0)
         self.ctx.check(self.lib.tsu_ising2d_row_ptr(self.h, int(local_row), C.byref(p), C.byref(pitch)))
         return p.value, pitch.value
+
+    def set_timing(self, enable=True):
+        self.ctx.check(self.lib.tsu_ising2d_set_timing(self.h, int(bool(enable))))
 
     def last_sweep_ms(self):
         ms = C.c_float(0)
