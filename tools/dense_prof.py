@@ -2,7 +2,7 @@ import sys; sys.path.insert(0,"tsu-emulator_amd"); sys.path.insert(0,".")
 import numpy as np
 from tsu import _hip as hip
 ctx = hip.Context.default()
-n=4096
+n=int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 rng = np.random.default_rng(42)
 G = rng.standard_normal((n, n)).astype(np.float32)
 J = ((G + G.T) / 2 / np.sqrt(n)).astype(np.float32)

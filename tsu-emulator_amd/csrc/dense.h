@@ -1,0 +1,77 @@
+// dense.h -- state of one dense coupling system (K2) and the device helpers its kernels share.
+#pragma once
+#include "tsu_common.h"
+
+#define DB 64  // block of visiting-order positions resolved by one wave
+
+struct tsu_dense {
+    tsu_ctx* ctx;
+    int n, dtype;
+    void* J;    // n x n row-major, f64 or f32
+    void* JT;   // transpose (aliases J when J is symmetric)
+    double* bias;
+    int8_t* state;   // current state ({0,1})
+    int8_t* state2;  // next state: a sweep reads `state` (frozen) and writes `state2`, then the two are swapped
+    double* field;
+    int* flips;      // per block: [0] = count, [1..DB] = site, delta pairs packed (site << 1 | (delta > 0))
+    int64_t* order;  // device copy of the visiting order (n_sweeps * n) or NULL
+    double* uniforms;
+    size_t order_cap, uni_cap;
+    double* d_energy;
+    // superblock fixed-point path
+    int8_t* delta[2];   // ping-pong flip vectors of the current superblock
+    double* logit;      // T * logit(u) per site of the current superblock... stored as logit(u)
+    int* sb_sync;       // [0 .. SB_MAX_IT): changes per iteration, [SB_MAX_IT]: converged flag, per superblock
+    int8_t* backup;     // state at the start of the call (re-run on the exact path if a superblock did not converge)
+    int sb_cap;         // superblocks allocated in sb_sync
+    int sb_budget;      // iteration launches per superblock: slowest fixed point of the last call + 8 (16 .. SB_MAX_IT)
+    // cooperative single-launch path (dense_coop.hip)
+    double* co_logit;   // logit(u) per site for the current sweep
+    double* co_corr;    // intra-superblock correction per site
+    int8_t* co_d0;      // flips decided from the field alone
+    int8_t* co_d1;      // current flips of the fixed-point iteration
+    int* co_lists;      // two change lists of SB_SIZE entries
+    int* co_counts;     // per (sweep, superblock): changes per iteration
+    unsigned* co_bar;   // grid barrier counter, error flag, slowest fixed point, not-converged flag
+    size_t co_counts_cap;
+    int co_disabled;    // cooperative launch unavailable or failed once: use the multi-launch path
+};
+
+
+#define SB_SIZE 2048  // positions per superblock of the fixed-point paths
+
+static __device__ __forceinline__ double dense_uniform(uint32_t i, uint32_t t, uint32_t tag, uint32_t k0, uint32_t k1) {
+    u32x4 w = tsu_philox(i >> 1, 0u, t, tag, k0, k1);
+    uint32_t a = (i & 1) ? w.z : w.x, b = (i & 1) ? w.w : w.y;
+    a >>= 5;
+    b >>= 6;
+    return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+}
+
+static __device__ __forceinline__ double sigmoid_clamped(double x) {
+    if (x > 20.0) return 1.0;
+    if (x < -20.0) return 0.0;
+    return 1.0 / (1.0 + exp(-x));
+}
+
+
+// u < sigmoid(x) <=> x > logit(u): the logit is computed once per site and sweep, so a decision is one compare
+// instead of a float64 exp.  The reference's own expression (gibbs.py:73-77,126) decides whenever x is within a
+// safety margin of the logit and at the +-20 clamp, so outcomes are unchanged.
+static __device__ __forceinline__ int dense_decide(double F, double lg, double T, double invT, uint32_t site,
+                                                   const double* __restrict__ uniforms, uint32_t sweep, uint32_t tag,
+                                                   uint32_t k0, uint32_t k1) {
+    const double xa = F * invT;
+    if (fabs(fabs(xa) - 20.0) < 1e-9 || fabs(xa - lg) <= 1e-9 * (1.0 + fabs(lg))) {
+        const double u = uniforms ? uniforms[site] : dense_uniform(site, sweep, tag, k0, k1);
+        return (u < sigmoid_clamped(F / T)) ? 1 : 0;
+    }
+    if (xa > 20.0) return 1;
+    if (xa < -20.0) return 0;
+    return xa > lg ? 1 : 0;
+}
+
+// cooperative single-launch sweep (dense_coop.hip): TSU_OK with *done = 1 when the call was carried out, *done = 0
+// when the path is unavailable or a superblock did not converge (state untouched or restored by the caller)
+int tsu_dense_coop_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint32_t sweep0, uint32_t replica,
+                         bool have_uni, int* done);

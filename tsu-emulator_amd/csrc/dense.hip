@@ -21,32 +21,7 @@
 #include <algorithm>
 #include <vector>
 
-#include "tsu_common.h"
-
-#define DB 64  // block of visiting-order positions resolved by one wave
-
-struct tsu_dense {
-    tsu_ctx* ctx;
-    int n, dtype;
-    void* J;    // n x n row-major, f64 or f32
-    void* JT;   // transpose (aliases J when J is symmetric)
-    double* bias;
-    int8_t* state;   // current state ({0,1})
-    int8_t* state2;  // next state: a sweep reads `state` (frozen) and writes `state2`, then the two are swapped
-    double* field;
-    int* flips;      // per block: [0] = count, [1..DB] = site, delta pairs packed (site << 1 | (delta > 0))
-    int64_t* order;  // device copy of the visiting order (n_sweeps * n) or NULL
-    double* uniforms;
-    size_t order_cap, uni_cap;
-    double* d_energy;
-    // superblock fixed-point path
-    int8_t* delta[2];   // ping-pong flip vectors of the current superblock
-    double* logit;      // T * logit(u) per site of the current superblock... stored as logit(u)
-    int* sb_sync;       // [0 .. SB_MAX_IT): changes per iteration, [SB_MAX_IT]: converged flag, per superblock
-    int8_t* backup;     // state at the start of the call (re-run on the exact path if a superblock did not converge)
-    int sb_cap;         // superblocks allocated in sb_sync
-    int sb_budget;      // iteration launches per superblock: slowest fixed point of the last call + 8 (16 .. SB_MAX_IT)
-};
+#include "dense.h"
 
 template <typename TJ>
 __global__ __launch_bounds__(256) void k2_matvec(const TJ* __restrict__ J, const int8_t* __restrict__ s,
@@ -59,20 +34,6 @@ __global__ __launch_bounds__(256) void k2_matvec(const TJ* __restrict__ J, const
     for (int j = lane; j < n; j += 64) acc += (double)row[j] * (double)s[j];
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if (lane == 0) f[wave] = acc + (bias ? bias[wave] : 0.0);
-}
-
-static __device__ __forceinline__ double dense_uniform(uint32_t i, uint32_t t, uint32_t tag, uint32_t k0, uint32_t k1) {
-    u32x4 w = tsu_philox(i >> 1, 0u, t, tag, k0, k1);
-    uint32_t a = (i & 1) ? w.z : w.x, b = (i & 1) ? w.w : w.y;
-    a >>= 5;
-    b >>= 6;
-    return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
-}
-
-static __device__ __forceinline__ double sigmoid_clamped(double x) {
-    if (x > 20.0) return 1.0;
-    if (x < -20.0) return 0.0;
-    return 1.0 / (1.0 + exp(-x));
 }
 
 // one wave resolves positions [pos0, pos0 + cnt) of the visiting order
@@ -276,7 +237,6 @@ __global__ __launch_bounds__(256) void k2_energy(const double* __restrict__ f, c
 // in about ten iterations.  A launch finds "no site changed in the previous iteration" and returns at once, so a
 // fixed launch budget costs little; if the budget is exhausted without convergence the whole call is re-run on the
 // block-by-block path (k2_block) from a backup of the state.  Natural visiting order only.
-#define SB_SIZE 2048
 #define SB_MAX_IT 32  // slots per superblock; the launch budget adapts below this
 
 template <typename TJ>
@@ -373,7 +333,6 @@ static int dense_sweep_superblocks(tsu_dense* d, double T, int n_sweeps, uint64_
         TSU_HIP_TRY(ctx, hipMalloc(&d->delta[0], SB_SIZE));
         TSU_HIP_TRY(ctx, hipMalloc(&d->delta[1], SB_SIZE));
         TSU_HIP_TRY(ctx, hipMalloc(&d->logit, SB_SIZE * sizeof(double)));
-        TSU_HIP_TRY(ctx, hipMalloc(&d->backup, (size_t)n));
     }
     if ((size_t)d->sb_cap < sync_ints) {
         if (d->sb_sync) (void)hipFree(d->sb_sync);
@@ -516,6 +475,7 @@ int tsu_dense_create(tsu_ctx* ctx, int n, const void* J_host, int dtype, const d
     if (e == hipSuccess) e = hipMalloc(&d->field, (size_t)n * 8);
     if (e == hipSuccess) e = hipMalloc(&d->flips, (DB + 1) * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&d->d_energy, 8);
+    if (e == hipSuccess) e = hipMalloc(&d->backup, (size_t)n);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (hostT) free(hostT);
     if (e != hipSuccess) {
@@ -545,6 +505,13 @@ int tsu_dense_destroy(tsu_dense* d) {
     if (d->logit) (void)hipFree(d->logit);
     if (d->sb_sync) (void)hipFree(d->sb_sync);
     if (d->backup) (void)hipFree(d->backup);
+    if (d->co_logit) (void)hipFree(d->co_logit);
+    if (d->co_corr) (void)hipFree(d->co_corr);
+    if (d->co_d0) (void)hipFree(d->co_d0);
+    if (d->co_d1) (void)hipFree(d->co_d1);
+    if (d->co_lists) (void)hipFree(d->co_lists);
+    if (d->co_counts) (void)hipFree(d->co_counts);
+    if (d->co_bar) (void)hipFree(d->co_bar);
     delete d;
     return TSU_OK;
 }
@@ -606,10 +573,23 @@ int tsu_dense_sweep(tsu_dense* d, double T, int n_sweeps, const int64_t* order, 
         TSU_HIP_TRY(ctx, hipMemcpyAsync(d->uniforms, replay_uniforms, cnt * 8, hipMemcpyHostToDevice, ctx->stream));
     }
     if (order || replay_uniforms) TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host buffers are the caller's
-    static int use_sb = -1;
+    static int use_sb = -1, use_coop = -1;
     if (use_sb < 0) {
         const char* e = getenv("TSU_K2_SUPERBLOCK");
         use_sb = e ? atoi(e) : 1;
+        e = getenv("TSU_K2_COOP");
+        use_coop = e ? atoi(e) : 1;
+    }
+    // natural order: the whole call in one cooperative launch; if that is unavailable, the same fixed point with one
+    // launch per iteration; the block-by-block path serves custom orders, tiny systems and a superblock that did not
+    // converge within its iteration slots
+    if (use_coop && !d->co_disabled && !order && d->n >= 2 * DB) {
+        TSU_HIP_TRY(ctx, hipMemcpyAsync(d->backup, d->state, (size_t)d->n, hipMemcpyDeviceToDevice, ctx->stream));
+        int done = 0;
+        int rc = tsu_dense_coop_sweep(d, T, n_sweeps, seed, sweep0, replica, replay_uniforms != nullptr, &done);
+        if (rc != TSU_OK) return rc;
+        if (done) return TSU_OK;
+        TSU_HIP_TRY(ctx, hipMemcpyAsync(d->state, d->backup, (size_t)d->n, hipMemcpyDeviceToDevice, ctx->stream));
     }
     if (use_sb && !order && d->n >= 2 * DB) {
         int ok = 0;
