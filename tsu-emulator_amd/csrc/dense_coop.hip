@@ -21,6 +21,7 @@
 #include "dense.h"
 
 #define CO_THREADS 1024
+#define CO_MAX_N 65536         // bytes of LDS for the staged state vector (phase A)
 #define CO_SLOTS 64            // iterations recorded per superblock; more than that = not converged (never seen)
 #define CO_TIMEOUT 400000000ll // wall_clock64 ticks (100 MHz): 4 s
 
@@ -45,13 +46,17 @@ struct CoopParams {
 };
 
 // ---------------------------------------------------------------------------------------------------- grid barrier
-// A flat counter costs 7.3 us per barrier for 256 workgroups (every arrival is a serialised memory-side atomic and
-// every workgroup pays an L2 write-back + invalidate).  This one is hierarchical over the XCDs (tools/microbench_gridbar3:
-// 2.4 us): workgroups arrive on their own XCD's counter (HW_REG_XCC_ID; counters and flags on separate 4 KiB pages);
-// the last arrival of an XCD -- by then every store of that XCD has reached its L2 (s_waitcnt vmcnt(0) precedes each
-// arrival) -- writes the L2 back, invalidates it, and arrives on the root counter; the last XCD raises one flag per
-// XCD.  Every other workgroup invalidates on wake-up (agent scope: its CU's L1 -- a workgroup-scope invalidate is
-// not enough, it leaves stale L1 lines and wrong results -- and the L2 again, which is cheap once it is clean).
+// A flat counter with agent-scope release/acquire fences costs 7.3 us per barrier for 256 workgroups: every arrival
+// is a serialised memory-side atomic and every workgroup pays an L2 write-back + invalidate.  Here
+//   * the barrier is hierarchical over the XCDs (HW_REG_XCC_ID): workgroups arrive on their own XCD's counter, the
+//     last arrival of an XCD arrives on the root counter, the last XCD raises one flag per XCD (counters and flags on
+//     separate 4 KiB pages): 1.9 us (tools/microbench_gridbar3.hip);
+//   * there are NO cache fences: everything one workgroup writes and another reads inside the kernel (fields, logits,
+//     corrections, flips, change lists, counters, state) goes through agent-scope relaxed atomic loads and stores,
+//     which are performed at the device's coherence point, past the per-CU L1 and the per-XCD L2 (the same property
+//     the barrier's own counters rely on).  J, the bias and replayed uniforms are read-only and cached normally.
+//     Vectors that every wave needs (the state in phase A, the flips in T and C) are staged once per workgroup into
+//     LDS.  A wave's stores are complete (s_waitcnt vmcnt(0)) before its workgroup arrives.
 #define BAR_PAGE 1024                 // unsigned per 4 KiB page
 #define BAR_GROUPS 16
 #define BAR_CNT(g) ((g) * BAR_PAGE)
@@ -107,9 +112,9 @@ static __device__ __forceinline__ bool grid_bar_init(GridBar& B, unsigned* bar) 
 }
 
 // false once a wait has expired anywhere in the grid (all workgroups then leave the kernel)
-static __device__ __forceinline__ bool grid_barrier(GridBar& B) {
+static __device__ __noinline__ bool grid_barrier(GridBar& B) {
     __shared__ int s_ok;  // one verdict per workgroup, so that all its threads leave (or stay) together
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached the L2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores are complete
     __syncthreads();
     B.epoch += 1;
     if (threadIdx.x == 0) {
@@ -117,14 +122,11 @@ static __device__ __forceinline__ bool grid_barrier(GridBar& B) {
         const unsigned a = __hip_atomic_fetch_add(&bar[BAR_CNT(B.g)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool leader = a + 1 == B.epoch * B.gsize;
         if (leader) {
-            asm volatile("buffer_wbl2 sc1\n s_waitcnt vmcnt(0)\n buffer_inv sc1\n s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned b = __hip_atomic_fetch_add(&bar[BAR_ROOT], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (b + 1 == B.epoch * B.ng)
                 for (int q = 0; q < BAR_GROUPS; ++q) __hip_atomic_store(&bar[BAR_GEN(q)], B.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        const bool ok = bar_wait(bar, &bar[BAR_GEN(B.g)], B.epoch);
-        if (!leader) asm volatile("buffer_inv sc1\n s_waitcnt vmcnt(0)" ::: "memory");
-        s_ok = ok;
+        s_ok = bar_wait(bar, &bar[BAR_GEN(B.g)], B.epoch);
     }
     __syncthreads();
     return s_ok != 0;
@@ -145,11 +147,54 @@ struct JVec<double> {
     static __device__ __forceinline__ double get(const raw& q, int e) { return e == 0 ? q.x : q.y; }
 };
 
-// wave-wide sum over columns [c0, c1) of row[j] * w[j], w an int8 vector with entries in {-1, 0, 1}.  c0 and the row
-// start are multiples of the vector width when VEC (checked by the host).  Eight 16-byte loads per lane are issued
-// before the first is consumed, also on short rows (out-of-range slots re-read the lane's first vector with weight 0).
+// dense_decide (dense.h) with the rare close call out of line: the float64 exp and the Philox block it needs would
+// otherwise be inlined at every decision site and push the kernel past its 128 VGPRs
+static __device__ __noinline__ int co_decide_exact(double F, double T, uint32_t site, const double* __restrict__ uniforms,
+                                                   uint32_t sweep, uint32_t tag, uint32_t k0, uint32_t k1) {
+    const double u = uniforms ? uniforms[site] : dense_uniform(site, sweep, tag, k0, k1);
+    return (u < sigmoid_clamped(F / T)) ? 1 : 0;
+}
+static __device__ __forceinline__ int co_decide(double F, double lg, double T, double invT, uint32_t site,
+                                                const double* __restrict__ uniforms, uint32_t sweep, uint32_t tag, uint32_t k0,
+                                                uint32_t k1) {
+    const double xa = F * invT;
+    if (fabs(fabs(xa) - 20.0) < 1e-9 || fabs(xa - lg) <= 1e-9 * (1.0 + fabs(lg)))
+        return co_decide_exact(F, T, site, uniforms, sweep, tag, k0, k1);
+    if (xa > 20.0) return 1;
+    if (xa < -20.0) return 0;
+    return xa > lg ? 1 : 0;
+}
+static __device__ __noinline__ double co_logit(uint32_t site, const double* __restrict__ uniforms, uint32_t sweep, uint32_t tag,
+                                               uint32_t k0, uint32_t k1) {
+    const double u = uniforms ? uniforms[site] : dense_uniform(site, sweep, tag, k0, k1);
+    return log(u) - log1p(-u);
+}
+
+// agent-scope accesses for data shared between workgroups inside the kernel (see the barrier's note)
+template <typename V>
+static __device__ __forceinline__ V ld(const V* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename V>
+static __device__ __forceinline__ void st(V* p, V v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the workgroup copies w[c0, c1) (c0 a multiple of 4) into LDS; the caller synchronises
+static __device__ __forceinline__ void stage_weights(const int8_t* w, int c0, int c1, int8_t* wl) {
+    const int nw4 = (c1 - c0) >> 2;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(w + c0);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(wl);
+    for (int q = threadIdx.x; q < nw4; q += CO_THREADS) dst[q] = ld(src + q);
+    for (int q = c0 + 4 * nw4 + threadIdx.x; q < c1; q += CO_THREADS) wl[q - c0] = ld(w + q);
+}
+
+// wave-wide sum over columns [c0, c1) of row[j] * wl[j - wbase], wl an int8 vector in LDS with entries in {-1, 0, 1}.
+// c0, wbase and the row start are multiples of the vector width when VEC (checked by the host).  Eight 16-byte loads
+// per lane are issued before the first is consumed, also on short rows (out-of-range slots re-read the lane's first
+// vector with weight 0).
 template <typename TJ, bool VEC>
-static __device__ __forceinline__ double wave_dot(const TJ* __restrict__ row, const int8_t* __restrict__ w, int c0, int c1,
+static __device__ __noinline__ double wave_dot(const TJ* __restrict__ row, const int8_t* wl, int wbase, int c0, int c1,
                                                   int lane) {
     double acc = 0.0;
     if (VEC) {
@@ -163,16 +208,18 @@ static __device__ __forceinline__ double wave_dot(const TJ* __restrict__ row, co
                 const int jq = j0 + q * 64 * W;
                 const bool ok = jq < c1v;
                 v[q] = *reinterpret_cast<const typename JVec<TJ>::raw*>(row + (ok ? jq : j0));
-                wp[q] = ok ? (W == 4 ? *reinterpret_cast<const uint32_t*>(w + jq) : (uint32_t)*reinterpret_cast<const uint16_t*>(w + jq)) : 0u;
+                wp[q] = ok ? (W == 4 ? *reinterpret_cast<const uint32_t*>(wl + (jq - wbase))
+                                     : (uint32_t)*reinterpret_cast<const uint16_t*>(wl + (jq - wbase)))
+                           : 0u;
             }
 #pragma unroll
             for (int q = 0; q < U; ++q)
 #pragma unroll
                 for (int e = 0; e < W; ++e) acc += JVec<TJ>::get(v[q], e) * (double)(int8_t)(wp[q] >> (8 * e));
         }
-        for (int t = c1v + lane; t < c1; t += 64) acc += (double)row[t] * (double)w[t];
+        for (int t = c1v + lane; t < c1; t += 64) acc += (double)row[t] * (double)wl[t - wbase];
     } else {
-        for (int j = c0 + lane; j < c1; j += 64) acc += (double)row[j] * (double)w[j];
+        for (int j = c0 + lane; j < c1; j += 64) acc += (double)row[j] * (double)wl[j - wbase];
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     return acc;  // valid in lane 0
@@ -199,6 +246,7 @@ __global__ __launch_bounds__(CO_THREADS) void k2_coop(CoopParams P) {
         tl[4 + kind] += 1;                             \
         tl_last = now_;                                \
     }
+    extern __shared__ int8_t wl[];  // staged weight vector: max(n, SB_SIZE) bytes
     int8_t* s = P.s0;
     int8_t* s_new = P.s1;
     int worst = 0;
@@ -206,15 +254,17 @@ __global__ __launch_bounds__(CO_THREADS) void k2_coop(CoopParams P) {
         const uint32_t t = P.sweep0 + (uint32_t)sw;
         const double* uni = P.uniforms ? P.uniforms + (size_t)sw * n : nullptr;
         // ---- A: field, logits, first guesses of superblock 0
+        stage_weights(s, 0, n, wl);
+        __syncthreads();
         for (int i = gw; i < n; i += NW) {
-            const double acc = wave_dot<TJ, VEC>(J + (size_t)i * n, s, 0, n, lane);
+            const double acc = wave_dot<TJ, VEC>(J + (size_t)i * n, wl, 0, 0, n, lane);
             if (lane == 0) {
                 const double F = acc + (P.bias ? P.bias[i] : 0.0);
-                const double u = uni ? uni[i] : dense_uniform((uint32_t)i, t, P.tag, P.k0, P.k1);
-                const double lg = log(u) - log1p(-u);
-                P.f[i] = F;
-                P.lg[i] = lg;
-                if (i < SB_SIZE) P.d0[i] = (int8_t)(dense_decide(F, lg, T, invT, (uint32_t)i, uni, t, P.tag, P.k0, P.k1) - (int)s[i]);
+                const double lg = co_logit((uint32_t)i, uni, t, P.tag, P.k0, P.k1);
+                st(P.f + i, F);
+                st(P.lg + i, lg);
+                if (i < SB_SIZE)
+                    st(P.d0 + i, (int8_t)(co_decide(F, lg, T, invT, (uint32_t)i, uni, t, P.tag, P.k0, P.k1) - (int)wl[i]));
             }
         }
         if (!grid_barrier(B)) return;
@@ -224,16 +274,21 @@ __global__ __launch_bounds__(CO_THREADS) void k2_coop(CoopParams P) {
             const int cnt = n - p0 < SB_SIZE ? n - p0 : SB_SIZE;
             const int pe = p0 + cnt;
             // ---- T: full triangular pass from the first guesses
+            stage_weights(P.d0, p0, pe, wl);
+            __syncthreads();
             for (int i = p0 + gw; i < pe; i += NW) {
-                const double acc = wave_dot<TJ, VEC>(J + (size_t)i * n, P.d0, p0, i, lane);
+                // the row's scalars travel together with its J loads, not after them
+                const double fi = ld(P.f + i), lgi = ld(P.lg + i);
+                const int si = ld(s + i);
+                const double acc = wave_dot<TJ, VEC>(J + (size_t)i * n, wl, p0, p0, i, lane);
                 if (lane == 0) {
-                    const int dold = P.d0[i];
-                    const int dn = dense_decide(P.f[i] + acc, P.lg[i], T, invT, (uint32_t)i, uni, t, P.tag, P.k0, P.k1) - (int)s[i];
-                    P.corr[i] = acc;
-                    P.d1[i] = (int8_t)dn;
+                    const int dold = wl[i - p0];
+                    const int dn = co_decide(fi + acc, lgi, T, invT, (uint32_t)i, uni, t, P.tag, P.k0, P.k1) - si;
+                    st(P.corr + i, acc);
+                    st(P.d1 + i, (int8_t)dn);
                     if (dn != dold) {
                         const int idx = atomicAdd(&counts[1], 1);
-                        P.lists[SB_SIZE + idx] = (i << 1) | (dn - dold > 0 ? 1 : 0);  // iteration 1 writes list 1
+                        st(P.lists + SB_SIZE + idx, (i << 1) | (dn - dold > 0 ? 1 : 0));  // iteration 1 writes list 1
                     }
                 }
             }
@@ -242,19 +297,21 @@ __global__ __launch_bounds__(CO_THREADS) void k2_coop(CoopParams P) {
             // ---- I: incremental iterations until nothing changes
             int k = 1;
             while (true) {
-                const int n_in = __hip_atomic_load(&counts[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int n_in = ld(&counts[k]);
                 if (n_in == 0) break;
                 if (k + 1 >= CO_SLOTS) {  // out of slots: report, leave the superblock as it is (the host redoes the call)
-                    if (gtid == 0) __hip_atomic_store(&P.bar[BAR_ERR + 2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (gtid == 0) st(&P.bar[BAR_ERR + 2], 1u);
                     break;
                 }
-                const int* __restrict__ lin = P.lists + (k & 1) * SB_SIZE;
-                int* __restrict__ lout = P.lists + ((k + 1) & 1) * SB_SIZE;
+                const int* lin = P.lists + (k & 1) * SB_SIZE;
+                int* lout = P.lists + ((k + 1) & 1) * SB_SIZE;
                 for (int i = p0 + gw; i < pe; i += NW) {
+                    const double fi = ld(P.f + i), lgi = ld(P.lg + i), ci = ld(P.corr + i);
+                    const int si = ld(s + i), dold = ld(P.d1 + i);
                     double acc = 0.0;
                     bool any = false;
                     for (int e = lane; e < n_in; e += 64) {
-                        const int v = lin[e], j = v >> 1;
+                        const int v = ld(lin + e), j = v >> 1;
                         if (j < i) {
                             const double x = (double)J[(size_t)i * n + j];
                             acc += (v & 1) ? x : -x;
@@ -264,14 +321,13 @@ __global__ __launch_bounds__(CO_THREADS) void k2_coop(CoopParams P) {
                     if (__ballot(any) == 0ull) continue;  // no earlier site changed: this row's decision stands
                     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
                     if (lane == 0) {
-                        const double c = P.corr[i] + acc;
-                        P.corr[i] = c;
-                        const int dold = P.d1[i];
-                        const int dn = dense_decide(P.f[i] + c, P.lg[i], T, invT, (uint32_t)i, uni, t, P.tag, P.k0, P.k1) - (int)s[i];
+                        const double c = ci + acc;
+                        st(P.corr + i, c);
+                        const int dn = co_decide(fi + c, lgi, T, invT, (uint32_t)i, uni, t, P.tag, P.k0, P.k1) - si;
                         if (dn != dold) {
-                            P.d1[i] = (int8_t)dn;
+                            st(P.d1 + i, (int8_t)dn);
                             const int idx = atomicAdd(&counts[k + 1], 1);
-                            lout[idx] = (i << 1) | (dn - dold > 0 ? 1 : 0);
+                            st(lout + idx, (i << 1) | (dn - dold > 0 ? 1 : 0));
                         }
                     }
                 }
@@ -281,14 +337,18 @@ __global__ __launch_bounds__(CO_THREADS) void k2_coop(CoopParams P) {
             }
             if (k > worst) worst = k;
             // ---- C: commit the superblock, add its flips to every later field, first guesses of the next superblock
-            for (int i = p0 + gtid; i < pe; i += NT) s_new[i] = (int8_t)(s[i] + P.d1[i]);
+            stage_weights(P.d1, p0, pe, wl);
+            __syncthreads();
+            for (int i = p0 + gtid; i < pe; i += NT) st(s_new + i, (int8_t)(ld(s + i) + wl[i - p0]));
             for (int r = pe + gw; r < n; r += NW) {
-                const double acc = wave_dot<TJ, VEC>(J + (size_t)r * n, P.d1, p0, pe, lane);
+                const bool next_sb = r < pe + SB_SIZE;
+                const double fr = ld(P.f + r), lgr = next_sb ? ld(P.lg + r) : 0.0;
+                const int sr = next_sb ? (int)ld(s + r) : 0;
+                const double acc = wave_dot<TJ, VEC>(J + (size_t)r * n, wl, p0, p0, pe, lane);
                 if (lane == 0) {
-                    const double F = P.f[r] + acc;
-                    P.f[r] = F;
-                    if (r < pe + SB_SIZE)
-                        P.d0[r] = (int8_t)(dense_decide(F, P.lg[r], T, invT, (uint32_t)r, uni, t, P.tag, P.k0, P.k1) - (int)s[r]);
+                    const double F = fr + acc;
+                    st(P.f + r, F);
+                    if (next_sb) st(P.d0 + r, (int8_t)(co_decide(F, lgr, T, invT, (uint32_t)r, uni, t, P.tag, P.k0, P.k1) - sr));
                 }
             }
             if (!grid_barrier(B)) return;
@@ -309,10 +369,17 @@ static int coop_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint3
     tsu_ctx* ctx = d->ctx;
     const int n = d->n;
     *done = 0;
+    if (n > CO_MAX_N) return TSU_OK;  // the staged state vector must fit in LDS: larger systems take the multi-launch path
     const bool vec = (n % JVec<TJ>::W) == 0;
     void (*kern)(CoopParams) = vec ? k2_coop<TJ, true> : k2_coop<TJ, false>;
+    const size_t lds_bytes = (size_t)((n > SB_SIZE ? n : SB_SIZE) + 15) / 16 * 16;
+    if (lds_bytes > 48 * 1024 &&
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return TSU_OK;
+    }
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, CO_THREADS, 0) != hipSuccess || per_cu < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, CO_THREADS, lds_bytes) != hipSuccess || per_cu < 1) {
         (void)hipGetLastError();
         d->co_disabled = 1;
         return TSU_OK;
@@ -367,7 +434,7 @@ static int coop_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint3
     const int useful = (n + CO_THREADS / 64 - 1) / (CO_THREADS / 64);
     if (grid > useful) grid = useful;
     void* args[] = {&P};
-    hipError_t e = hipLaunchCooperativeKernel((const void*)kern, dim3((unsigned)grid), dim3(CO_THREADS), args, 0, ctx->stream);
+    hipError_t e = hipLaunchCooperativeKernel((const void*)kern, dim3((unsigned)grid), dim3(CO_THREADS), args, (unsigned)lds_bytes, ctx->stream);
     if (e != hipSuccess) {  // no cooperative launch on this device / configuration: not an error, use the other path
         (void)hipGetLastError();
         d->co_disabled = 1;
