@@ -38,7 +38,7 @@ struct tsu_dense {
 };
 
 
-#define SB_SIZE 2048  // positions per superblock of the fixed-point paths
+#define SB_SIZE 4096  // positions per superblock of the fixed-point paths (4096 beats 2048 and 8192: profiles/r01_k2_notes.txt)
 
 static __device__ __forceinline__ double dense_uniform(uint32_t i, uint32_t t, uint32_t tag, uint32_t k0, uint32_t k1) {
     u32x4 w = tsu_philox(i >> 1, 0u, t, tag, k0, k1);
