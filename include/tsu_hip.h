@@ -146,6 +146,15 @@ int tsu_dense_get_state(tsu_dense* d, int8_t* bits_host);
  * sweep0+s) or n_sweeps*n doubles consumed in visiting order (replays np.random.rand, gibbs.py:126). */
 int tsu_dense_sweep(tsu_dense* d, double T, int n_sweeps, const int64_t* order, uint64_t seed, uint32_t sweep0,
                     uint32_t replica, const double* replay_uniforms);
+/* The whole sampling run of GibbsSampler.sample_boltzmann (tsu/gibbs.py:196-213) from the resident state:
+ * n_burnin sweeps, then n_samples x (n_sweeps sweeps, record the state).  samples_host receives n_samples*n bits.
+ * order / replay_uniforms cover all (n_burnin + n_samples*n_sweeps) sweeps, row per sweep; sweep numbers for the
+ * Philox stream count on from sweep0.  Systems of n <= 64 sites in natural order run as ONE launch of a single
+ * wave (the reference's published benchmark sizes: n = 1 and n = 10); larger ones loop tsu_dense_sweep on the device
+ * side and copy the samples back once. */
+int tsu_dense_sample(tsu_dense* d, double T, int n_burnin, int n_sweeps, int n_samples, const int64_t* order,
+                     uint64_t seed, uint32_t sweep0, uint32_t replica, const double* replay_uniforms,
+                     int8_t* samples_host);
 int tsu_dense_energy(tsu_dense* d, double* energy); /* -1/2 s^T J s - b^T s of the resident state */
 
 /* ------------------------------------------------------------------ Langevin (K3)

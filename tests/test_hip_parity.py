@@ -271,6 +271,37 @@ def test_dense_superblocks_match_oracle(hip, n, dtype, T, sym):
     d.close()
 
 
+@pytest.mark.parametrize("n", [1, 10, 64, 65, 200])
+def test_dense_sample_run_matches_oracle(hip, n):
+    """tsu_dense_sample (burn-in + n_samples x n_sweeps in one call; a single wave for n <= 64) against the oracle's
+    sweep-by-sweep chain: Philox uniforms, replayed uniforms, and (n > 64 path) a permuted order."""
+    rng = np.random.default_rng(100 + n)
+    J = rng.normal(size=(n, n)) / max(1.0, np.sqrt(n))
+    J = (J + J.T) / 2
+    b = rng.normal(size=n) * 0.4
+    st = rng.integers(0, 2, size=n).astype(np.int8)
+    T, burn, ns, m, seed = 0.8, 7, 3, 5, 31337
+    d = hip.DenseSystem(J, b)
+    d.set_state(st)
+    got = d.sample(T, burn, ns, m, seed=seed, sweep0=11)
+    cur = ora.dense_sweep_philox(st, J, b, T, burn, seed, sweep0=11)
+    for k in range(m):
+        cur = ora.dense_sweep_philox(cur, J, b, T, ns, seed, sweep0=11 + burn + k * ns)
+        np.testing.assert_array_equal(got[k], cur)
+    np.testing.assert_array_equal(d.get_state(), cur)  # the run leaves the last state resident
+    total = burn + m * ns
+    u = rng.random(size=(total, n))
+    order = np.array([rng.permutation(n) for _ in range(total)]) if n > 64 else None
+    d.set_state(st)
+    got = d.sample(T, burn, ns, m, order=order, replay_uniforms=u)
+    cur = ora.c_dense_sweep_replay(st, J, b, T, u[:burn], None if order is None else order[:burn])
+    for k in range(m):
+        lo = burn + k * ns
+        cur = ora.c_dense_sweep_replay(cur, J, b, T, u[lo:lo + ns], None if order is None else order[lo:lo + ns])
+        np.testing.assert_array_equal(got[k].astype(np.int64), cur)
+    d.close()
+
+
 def test_dense_golden_replay_on_device(hip, golden):
     """The reference's own seeded run (tests/golden/g1, g2) reproduced by the HIP kernel with replayed MT19937 draws."""
     for name in ("g1_dense_sequential", "g2_dense_random"):

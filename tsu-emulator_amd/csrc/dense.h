@@ -34,6 +34,8 @@ struct tsu_dense {
     int* co_counts;     // per (sweep, superblock): changes per iteration
     unsigned* co_bar;   // grid barrier counter, error flag, slowest fixed point, not-converged flag
     size_t co_counts_cap;
+    int8_t* samples;    // device buffer of recorded states (tsu_dense_sample)
+    size_t samples_cap;
     int co_disabled;    // cooperative launch unavailable or failed once: use the multi-launch path
 };
 

@@ -213,6 +213,67 @@ __global__ __launch_bounds__(256) void k2_block(const TJ* __restrict__ J, const 
     }
 }
 
+// ================================================================== small systems: one wave, one launch per run
+// n <= 64 sites, natural order: the whole sample_boltzmann run (burn-in, then n_samples x n_sweeps sweeps with a
+// recorded state after each group) inside one wave.  Lane k owns site k; J sits in LDS as columns; every sweep
+// recomputes the fields from scratch (like the reference's np.dot per site) and resolves the sequential pass by jumping from flip to flip (ballot + ffs) as k2_block does.
+template <typename TJ>
+__global__ __launch_bounds__(64) void k2_small(const TJ* __restrict__ J, const double* __restrict__ bias, int8_t* __restrict__ state,
+                                              const double* __restrict__ uniforms, int8_t* __restrict__ samples, int n, double T,
+                                              int n_burnin, int n_sweeps, int n_samples, uint32_t sweep0, uint32_t tag, uint32_t k0,
+                                              uint32_t k1) {
+    __shared__ double col[DB][DB + 1];  // col[i][k] = J[k][i]
+    const int lane = threadIdx.x;
+    const bool on = lane < n;
+    for (int i = 0; i < n; ++i) col[i][lane] = on ? (double)J[(size_t)lane * n + i] : 0.0;
+    __syncthreads();
+    const double bk = (on && bias) ? bias[lane] : 0.0;
+    const double invT = 1.0 / T;
+    int bit = on ? state[lane] : 0;
+    const int total = n_burnin + n_samples * n_sweeps;
+    int next_record = n_burnin + n_sweeps - 1, rec = 0;
+    double u_next = (on && uniforms && total > 0) ? uniforms[lane] : 2.0;
+    for (int sw = 0; sw < total; ++sw) {
+        double u = 2.0;
+        if (on) u = uniforms ? u_next : dense_uniform((uint32_t)lane, sweep0 + (uint32_t)sw, tag, k0, k1);
+        if (on && uniforms && sw + 1 < total) u_next = uniforms[(size_t)(sw + 1) * n + lane];  // in flight during this sweep
+        const unsigned long long up = __ballot(bit != 0);
+        double fk = bk;
+        for (int i = 0; i < n; ++i) {  // ascending i, all LDS reads independent of the adds
+            const double c = col[i][lane];
+            if ((up >> i) & 1ull) fk += c;
+        }
+        // u < sigmoid(x): a float32 sigmoid settles it unless u is within 1e-5 of it (or x within 1e-3 of the +-20
+        // clamp); those rare cases take the reference's float64 expression (gibbs.py:73-77,126), so outcomes are its
+        const float uf = (float)u;
+        int cursor = 0;
+        while (true) {
+            const float xf = (float)(fk * invT);
+            int cand;
+            if (fabsf(fabsf(xf) - 20.0f) < 1e-3f) cand = (u < sigmoid_clamped(fk / T)) ? 1 : 0;
+            else if (xf > 20.0f) cand = 1;
+            else if (xf < -20.0f) cand = 0;
+            else {
+                const float du = uf - 1.0f / (1.0f + __expf(-xf));
+                cand = fabsf(du) <= 1e-5f ? ((u < sigmoid_clamped(fk / T)) ? 1 : 0) : (du < 0.0f ? 1 : 0);
+            }
+            const unsigned long long want = __ballot(on && lane >= cursor && cand != bit);
+            if (want == 0ull) break;
+            const int i = __ffsll((long long)want) - 1;
+            const int delta = __shfl(cand - bit, i, 64);
+            if (lane == i) bit = cand;
+            fk += (double)delta * col[i][lane];
+            cursor = i + 1;
+        }
+        if (sw == next_record) {
+            if (on) samples[(size_t)rec * n + lane] = (int8_t)bit;
+            ++rec;
+            next_record += n_sweeps;
+        }
+    }
+    if (on) state[lane] = (int8_t)bit;
+}
+
 __global__ __launch_bounds__(256) void k2_energy(const double* __restrict__ f, const int8_t* __restrict__ s,
                                                 const double* __restrict__ bias, double* __restrict__ out, int n) {
     // f = J s + b  =>  -1/2 s.(f - b) - b.s
@@ -505,6 +566,7 @@ int tsu_dense_destroy(tsu_dense* d) {
     if (d->logit) (void)hipFree(d->logit);
     if (d->sb_sync) (void)hipFree(d->sb_sync);
     if (d->backup) (void)hipFree(d->backup);
+    if (d->samples) (void)hipFree(d->samples);
     if (d->co_logit) (void)hipFree(d->co_logit);
     if (d->co_corr) (void)hipFree(d->co_corr);
     if (d->co_d0) (void)hipFree(d->co_d0);
@@ -612,6 +674,67 @@ int tsu_dense_sweep(tsu_dense* d, double T, int n_sweeps, const int64_t* order, 
     if (d->dtype == TSU_DTYPE_F64)
         return dense_sweep_impl<double>(d, T, n_sweeps, order != nullptr, seed, sweep0, replica, replay_uniforms != nullptr);
     return dense_sweep_impl<float>(d, T, n_sweeps, order != nullptr, seed, sweep0, replica, replay_uniforms != nullptr);
+}
+
+int tsu_dense_sample(tsu_dense* d, double T, int n_burnin, int n_sweeps, int n_samples, const int64_t* order, uint64_t seed,
+                     uint32_t sweep0, uint32_t replica, const double* replay_uniforms, int8_t* samples_host) {
+    if (!d) return TSU_E_INVALID;
+    tsu_ctx* ctx = d->ctx;
+    TSU_REQUIRE(ctx, T > 0.0, "Temperature must be positive");
+    TSU_REQUIRE(ctx, n_burnin >= 0 && n_sweeps > 0 && n_samples >= 0, "dense_sample: need n_burnin >= 0, n_sweeps > 0, n_samples >= 0");
+    TSU_REQUIRE(ctx, n_samples == 0 || samples_host != nullptr, "dense_sample: NULL output");
+    const long long total = (long long)n_burnin + (long long)n_samples * n_sweeps;
+    TSU_REQUIRE(ctx, total <= (1ll << 30) && (uint64_t)sweep0 + (uint64_t)total <= (1ull << 32), "dense_sample: sweep counter overflow");
+    const int n = d->n;
+    const size_t out_bytes = (size_t)n_samples * n;
+    if (d->samples_cap < out_bytes) {
+        if (d->samples) (void)hipFree(d->samples);
+        d->samples = nullptr;
+        d->samples_cap = 0;
+        TSU_HIP_TRY(ctx, hipMalloc(&d->samples, out_bytes));
+        d->samples_cap = out_bytes;
+    }
+    if (n <= DB && !order) {
+        const size_t cnt = (size_t)total * n;
+        if (replay_uniforms && cnt) {
+            if (d->uni_cap < cnt) {
+                if (d->uniforms) (void)hipFree(d->uniforms);
+                d->uniforms = nullptr;
+                d->uni_cap = 0;
+                TSU_HIP_TRY(ctx, hipMalloc(&d->uniforms, cnt * 8));
+                d->uni_cap = cnt;
+            }
+            TSU_HIP_TRY(ctx, hipMemcpyAsync(d->uniforms, replay_uniforms, cnt * 8, hipMemcpyHostToDevice, ctx->stream));
+        }
+        const uint32_t tag = TSU_TAG_DENSE | (replica << 8);
+        if (total > 0) {
+            if (d->dtype == TSU_DTYPE_F64)
+                k2_small<double><<<1, 64, 0, ctx->stream>>>((const double*)d->J, d->bias, d->state, replay_uniforms ? d->uniforms : nullptr,
+                                                            d->samples, n, T, n_burnin, n_sweeps, n_samples, sweep0, tag, (uint32_t)seed,
+                                                            (uint32_t)(seed >> 32));
+            else
+                k2_small<float><<<1, 64, 0, ctx->stream>>>((const float*)d->J, d->bias, d->state, replay_uniforms ? d->uniforms : nullptr,
+                                                           d->samples, n, T, n_burnin, n_sweeps, n_samples, sweep0, tag, (uint32_t)seed,
+                                                           (uint32_t)(seed >> 32));
+            TSU_HIP_TRY(ctx, hipGetLastError());
+        }
+    } else {
+        // larger systems: the sweep paths above, one call per recorded state; samples gathered on the device
+        int rc = tsu_dense_sweep(d, T, n_burnin, order, seed, sweep0, replica, replay_uniforms);
+        if (rc != TSU_OK) return rc;
+        size_t off = (size_t)n_burnin * n;
+        uint32_t sw = sweep0 + (uint32_t)n_burnin;
+        for (int k = 0; k < n_samples; ++k) {
+            rc = tsu_dense_sweep(d, T, n_sweeps, order ? order + off : nullptr, seed, sw, replica, replay_uniforms ? replay_uniforms + off : nullptr);
+            if (rc != TSU_OK) return rc;
+            TSU_HIP_TRY(ctx, hipMemcpyAsync(d->samples + (size_t)k * n, d->state, (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+            off += (size_t)n_sweeps * n;
+            sw += (uint32_t)n_sweeps;
+        }
+    }
+    if (out_bytes) TSU_HIP_TRY(ctx, hipMemcpyAsync(samples_host, d->samples, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TSU_OK;
 }
 
 int tsu_dense_energy(tsu_dense* d, double* energy) {

@@ -178,13 +178,43 @@ class GibbsSampler:
             state = np.random.randint(0, 2, size=n_bits)
         sys = self._system(coupling, bias)
         sys.set_state(self._as_bits(state, n_bits))
-        self._run_sweeps(sys, int(burnin))
         samples = np.zeros((n_samples, n_bits), dtype=int)
-        for i in range(n_samples):
-            self._run_sweeps(sys, int(self.config.n_sweeps))
-            samples[i] = sys.get_state()
-            self.sample_count += 1
+        # the whole run (burn-in, then n_samples x n_sweeps sweeps) in as few device calls as the draw buffers allow
+        n_sweeps = int(self.config.n_sweeps)
+        chunk = max(1, min(int(n_samples), (1 << 23) // max(1, n_sweeps * n_bits)))  # <= 64 MiB of replayed doubles per call
+        done, burn = 0, int(burnin)
+        if n_samples == 0:
+            self._run_sweeps(sys, burn)
+        while done < n_samples:
+            m = min(chunk, n_samples - done)
+            samples[done:done + m] = self._run_sampling(sys, burn, n_sweeps, m)
+            self.sample_count += m
+            done += m
+            burn = 0
         return samples
+
+    def _run_sampling(self, sys: "_hip.DenseSystem", n_burnin: int, n_sweeps: int, n_samples: int) -> np.ndarray:
+        """n_burnin sweeps, then n_samples x (n_sweeps sweeps, record) at the current temperature: one C call."""
+        n, T = sys.n, float(self.config.temperature)
+        if T <= 0:
+            raise ValueError("Temperature must be positive")
+        total = n_burnin + n_samples * n_sweeps
+        random_order = self.config.update_order == "random"
+        if self.rng == "numpy":
+            # the reference's draw order (gibbs.py:152-160): per sweep [permutation(n)] then one rand() per visited site
+            if random_order:
+                order = np.empty((total, n), dtype=np.int64)
+                uni = np.empty((total, n), dtype=np.float64)
+                for s in range(total):
+                    order[s] = np.random.permutation(n)
+                    uni[s] = np.random.rand(n)
+            else:
+                order, uni = None, np.random.rand(total, n)
+            return sys.sample(T, n_burnin, n_sweeps, n_samples, order=order, replay_uniforms=uni)
+        order = np.array([np.random.permutation(n) for _ in range(total)]).reshape(total, n) if random_order else None
+        out = sys.sample(T, n_burnin, n_sweeps, n_samples, seed=self._philox_seed(), sweep0=self._sweep_counter, order=order)
+        self._sweep_counter += total
+        return out
 
     def sample(self, J: np.ndarray, n_samples: int = 1000, bias: Optional[np.ndarray] = None) -> np.ndarray:
         """README name (README.md:79) for :meth:`sample_boltzmann`."""
