@@ -285,7 +285,7 @@ def main():
                                  "on the launch stream over the timed region); the kernel keeps the tile in LDS for k "
                                  "sweeps, so real HBM traffic is ~2/k B per update and the kernel is VALU (Philox) bound"},
             "observables": {"M": s / (float(L) * L * world), "E_per_site": -b / (float(L) * L * world),
-                            "note": "physical mode, random start, far from equilibrium at T_c (critical slowing down)"},
+                            "note": "physical mode, random start; u(T_c) = -sqrt(2) = -1.4142 is approached slowly (critical slowing down)"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(L)
@@ -296,7 +296,7 @@ def main():
             lat.close()
             extra = {}
             for L2, k2 in ((8192, 5), (16384, 5)):
-                extra[f"ising2d_L{L2}"] = time_lattice(hip, ctx, L2, k2, 40)
+                extra[f"ising2d_L{L2}"] = time_lattice(hip, ctx, L2, k2, 120)
             extra["langevin_dim_2^20"] = time_langevin(hip, ctx)
             extra["dense_gibbs"] = time_dense(hip, ctx)
             out["extra"] = extra
