@@ -65,25 +65,27 @@ def test_ising2d_sweep_bit_exact(hip, rows, cols, periodic, kernel):
 TILED_LATTICES = [(96, 544), (128, 1024), (130, 560), (200, 2080), (256, 4096)]
 
 
+@pytest.mark.parametrize("periodic", [True, False])
 @pytest.mark.parametrize("spl", [1, 2, 3, 8])
 @pytest.mark.parametrize("rows,cols", TILED_LATTICES)
-def test_ising2d_tiled_kernel_bit_exact(hip, rows, cols, spl):
-    """LDS-tiled multi-sweep kernel == oracle == generic kernel, for any sweeps-per-launch."""
+def test_ising2d_tiled_kernel_bit_exact(hip, rows, cols, spl, periodic):
+    """LDS-tiled multi-sweep kernel == oracle == generic kernel, for any sweeps-per-launch; periodic lattices and
+    open ones (the reference's default, ising.py:320-326: edge sites have degree 3, corners 2, own thresholds)."""
     seed = 555 + rows + cols
     s0 = ora.ising2d_randomize(rows, cols, seed)
     for (J, h, T, mode) in [(1.0, 0.0, 2.269185, hip.MODE_PHYSICAL), (-0.7, 0.3, 1.1, hip.MODE_COMPAT)]:
         table = ora.ising2d_thresholds(J, h, T, mode)
-        lat = hip.Lattice(rows, cols, True)
+        lat = hip.Lattice(rows, cols, periodic)
         lat.set_kernel(hip.KERNEL_TILED, spl)
         lat.set_spins(s0)
         lat.set_thresholds(table)
         lat.sweep(1, seed, sweep0=0)
-        want = ora.ising2d_sweep(s0, True, table, 1, seed, sweep0=0)
+        want = ora.ising2d_sweep(s0, periodic, table, 1, seed, sweep0=0)
         np.testing.assert_array_equal(lat.get_spins(), want)
         lat.sweep(11, seed, sweep0=1)
-        want = ora.ising2d_sweep(want, True, table, 11, seed, sweep0=1)
+        want = ora.ising2d_sweep(want, periodic, table, 11, seed, sweep0=1)
         np.testing.assert_array_equal(lat.get_spins(), want)
-        assert lat.observables() == ora.ising2d_observables(want, True)
+        assert lat.observables() == ora.ising2d_observables(want, periodic)
         lat.close()
 
 
@@ -94,24 +96,28 @@ def test_ising2d_tiled_ties_and_clamps(hip):
     for table in (np.array([(k * 0x0A3D) << 16 | 0x8000 for k in range(25)], dtype=np.uint64),
                   np.array([0, 1 << 32, 1, (1 << 32) - 1, 65536] * 5, dtype=np.uint64),
                   np.array([0xFFFF0000, 0x00010000, 0xFFFFFFFF, 0x0000FFFF, 0x80000000] * 5, dtype=np.uint64)):
-        lat = hip.Lattice(rows, cols, True)
-        lat.set_kernel(hip.KERNEL_TILED, 4)
-        lat.set_spins(s0)
-        lat.set_thresholds(table)
-        lat.sweep(9, 99, sweep0=11)
-        np.testing.assert_array_equal(lat.get_spins(), ora.ising2d_sweep(s0, True, table, 9, 99, sweep0=11))
+        for periodic in (True, False):
+            lat = hip.Lattice(rows, cols, periodic)
+            lat.set_kernel(hip.KERNEL_TILED, 4)
+            lat.set_spins(s0)
+            lat.set_thresholds(table)
+            lat.sweep(9, 99, sweep0=11)
+            np.testing.assert_array_equal(lat.get_spins(), ora.ising2d_sweep(s0, periodic, table, 9, 99, sweep0=11))
+            lat.close()
 
 
 @pytest.mark.parametrize("nslab,ghost,k,spl", [(2, 8, 4, 0), (3, 16, 8, 0), (2, 2, 1, 0), (2, 32, 16, 4), (2, 40, 19, 8),
                                                 (3, 24, 12, 5)])
-def test_ising2d_tiled_slabs(hip, nslab, ghost, k, spl):
+@pytest.mark.parametrize("periodic", [True, False])
+def test_ising2d_tiled_slabs(hip, nslab, ghost, k, spl, periodic):
     """Row slabs driven through the tiled kernel (ghost rows as the vertical halo) == whole lattice; with
-    k > sweeps-per-launch a slab sweeps several launches per ghost refresh, extending into its ghost rows."""
+    k > sweeps-per-launch a slab sweeps several launches per ghost refresh, extending into its ghost rows.
+    Open lattices: the outer slabs' ghost rows lie beyond the lattice and count as empty."""
     per, cols, seed = 128, 576, 31
     rows = per * nslab
-    table = ora.ising2d_thresholds(1.0, 0.0, 2.269185, 0)
+    table = ora.ising2d_thresholds(1.0, 0.1, 2.269185, 0)
     full = ora.ising2d_randomize(rows, cols, seed)
-    slabs = [hip.Lattice(per, cols, True, total_rows=rows, row0=i * per, ghost=ghost) for i in range(nslab)]
+    slabs = [hip.Lattice(per, cols, periodic, total_rows=rows, row0=i * per, ghost=ghost) for i in range(nslab)]
     for i, s in enumerate(slabs):
         s.set_kernel(hip.KERNEL_TILED, spl)
         s.set_spins(full[i * per:(i + 1) * per])
@@ -120,11 +126,13 @@ def test_ising2d_tiled_slabs(hip, nslab, ghost, k, spl):
     for it in range(3):
         owned = [s.get_spins() for s in slabs]
         for i, s in enumerate(slabs):
-            s.set_spins(owned[(i - 1) % nslab][-ghost:], row_first=-ghost)
-            s.set_spins(owned[(i + 1) % nslab][:ghost], row_first=per)
+            if periodic or i > 0:
+                s.set_spins(owned[(i - 1) % nslab][-ghost:], row_first=-ghost)
+            if periodic or i < nslab - 1:
+                s.set_spins(owned[(i + 1) % nslab][:ghost], row_first=per)
         for s in slabs:
             s.sweep(k, seed, sweep0=it * k)
-        want = ora.ising2d_sweep(want, True, table, k, seed, sweep0=it * k)
+        want = ora.ising2d_sweep(want, periodic, table, k, seed, sweep0=it * k)
         np.testing.assert_array_equal(np.concatenate([s.get_spins() for s in slabs]), want)
 
 

@@ -7,7 +7,7 @@ from tsu import _hip
 ctx = _hip.Context.default()
 Ls = [int(a) for a in sys.argv[1:]] or [4096, 8192]
 for L in Ls:
-    lat = _hip.Lattice(L, L, True)
+    lat = _hip.Lattice(L, L, os.environ.get("OPEN", "0") != "1")
     lat.randomize(42)
     lat.set_model(1.0, 0.0, 2.269185)
     for spl, n in [(int(x), 60) for x in os.environ.get("KS", "3,4,5,6").split(",")]:

@@ -33,7 +33,9 @@ struct TiledParams {
     int debug;                   // development timing aid (TSU_K1_DEBUG): 1 = skip HBM loads, 2 = skip loads and stores
     uint32_t k0, k1, sweep0, tag_hi, tag_lo;
     uint32_t tblH0, tblH1, tblL0, tblL1;  // (min(thr >> 16, 65535) ^ 0x8000) for up = 0..4, split into byte tables
-    uint64_t thr[5];                      // full thresholds (degree 4) for the tie path
+    uint32_t t3H0, t3H1, t3L0, t3L1;      // open lattices: the same for degree 3 (entries 0..3) and degree 2 (entries 4..6)
+    int open;                             // open boundary: sites outside the lattice count as 0 "up" and lower the degree
+    uint64_t thr[25];                     // full thresholds, [deg * 5 + up], for the tie path
 };
 
 static __device__ __forceinline__ uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel) {
@@ -50,22 +52,26 @@ static __device__ __forceinline__ uint32_t minu16(uint32_t a, uint32_t b) {
 // Cold path (probability 2^-16 per site): kept out of line and register-to-register (no arrays by address).
 static __device__ __noinline__ u32x4 resolve_ties(u32x4 d, u32x4 w, uint32_t cnt_lo, uint32_t cnt_hi, const uint64_t* s_thr,
                                                   uint32_t cq, uint32_t Rg, uint32_t hs, uint32_t tag_lo, uint32_t k0,
-                                                  uint32_t k1) {
+                                                  uint32_t k1, uint32_t edge = 0) {
+    // edge (open lattices): bit 0 = the row is the lattice's top or bottom row, bit 1 = site 0 of the octet is in the
+    // lattice's first column, bit 2 = site 7 is in its last column; degree = 4 minus the missing neighbours
     const u32x4 l = tsu_philox(cq, Rg, hs, tag_lo, k0, k1);
-#define TSU_FIX(DW, WW, LW, CNT, B0)                                                                            \
+#define TSU_FIX(DW, WW, LW, CNT, B0, M0)                                                                        \
     _Pragma("unroll") for (int hlf = 0; hlf < 2; ++hlf) {                                                       \
         const uint32_t sh = 16u * hlf;                                                                          \
         if (((DW >> sh) & 0xFFFFu) == 0) {                                                                      \
             const uint32_t c = (CNT >> (8 * (B0 + hlf))) & 0xFFu;                                               \
+            const uint32_t m = M0 + hlf;                                                                        \
+            const uint32_t deg = 4u - (edge & 1u) - ((m == 0 && (edge & 2u)) ? 1u : 0u) - ((m == 7 && (edge & 4u)) ? 1u : 0u); \
             const uint64_t u = ((uint64_t)(((WW >> sh) & 0xFFFFu) ^ 0x8000u) << 16) | ((LW >> sh) & 0xFFFFu);   \
-            const uint32_t f = (u < s_thr[c]) ? 0x8000u : 0x0001u; /* negative field = accept */                \
+            const uint32_t f = (u < s_thr[deg * 5 + c]) ? 0x8000u : 0x0001u; /* negative field = accept */      \
             DW = (DW & ~(0xFFFFu << sh)) | (f << sh);                                                           \
         }                                                                                                       \
     }
-    TSU_FIX(d.x, w.x, l.x, cnt_lo, 0)
-    TSU_FIX(d.y, w.y, l.y, cnt_lo, 2)
-    TSU_FIX(d.z, w.z, l.z, cnt_hi, 0)
-    TSU_FIX(d.w, w.w, l.w, cnt_hi, 2)
+    TSU_FIX(d.x, w.x, l.x, cnt_lo, 0, 0)
+    TSU_FIX(d.y, w.y, l.y, cnt_lo, 2, 2)
+    TSU_FIX(d.z, w.z, l.z, cnt_hi, 0, 4)
+    TSU_FIX(d.w, w.w, l.w, cnt_hi, 2, 6)
 #undef TSU_FIX
     return d;
 }
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(THREADS) void k1_tiled(TiledParams p) {
     uint64_t* plane1 = plane0 + TR * NO;
     uint64_t* s_thr = plane1 + TR * NO + 1;
     const int tid = threadIdx.x;
-    if (tid < 5) s_thr[tid] = p.thr[tid];
+    if (tid < 25) s_thr[tid] = p.thr[tid];
 
     const int tx = blockIdx.x % p.tiles_x, ty = p.ty_first + (blockIdx.x / p.tiles_x) * p.ty_stride;
     const int q0 = tx * WO;      // first interior chunk (16 columns each)
@@ -286,6 +292,10 @@ struct Rows2Ctx {
     int total_rows;
     uint32_t hs, tag_hi, tag_lo, k0, k1;
     uint32_t tblH0, tblH1, tblL0, tblL1;
+    uint32_t t3H0, t3H1, t3L0, t3L1;  // open lattices: degree 3 / degree 2 byte tables
+    int last_row;                     // open lattices: global index of the lattice's bottom row
+    bool lft, rgt;                    // open lattices: this thread's octet holds the lattice's first / last column
+    bool col_out;                     // open lattices: this thread's octet lies beyond the lattice (stays empty)
 };
 
 // thresholds for the 8 sites of one octet given their up-counts, compared with one Philox block: d < 0 = accept
@@ -293,6 +303,30 @@ static __device__ __forceinline__ u32x4 compare_octet(const u32x4& w, uint32_t c
                                                       uint32_t tH1, uint32_t tL0, uint32_t tL1) {
     const uint32_t Hl = perm(tH1, tH0, cnt_lo), Ll = perm(tL1, tL0, cnt_lo);
     const uint32_t Hh = perm(tH1, tH0, cnt_hi), Lh = perm(tL1, tL0, cnt_hi);
+    u32x4 d;
+    d.x = subsat16(w.x, perm(Hl, Ll, 0x05010400u));
+    d.y = subsat16(w.y, perm(Hl, Ll, 0x07030602u));
+    d.z = subsat16(w.z, perm(Hh, Lh, 0x05010400u));
+    d.w = subsat16(w.w, perm(Hh, Lh, 0x07030602u));
+    return d;
+}
+
+// Open lattices: as compare_octet, then the sites with fewer than four neighbours take their thresholds from the
+// degree-3 / degree-2 table instead (row_edge: the whole row is the lattice's top or bottom row; l0 / r7: site 0 /
+// site 7 of the octet sits in the lattice's first / last column).  Only executed by waves that hold such a site.
+static __device__ __forceinline__ u32x4 compare_octet_open(const u32x4& w, uint32_t cnt_lo, uint32_t cnt_hi, const Rows2Ctx& c,
+                                                           bool row_edge, bool l0, bool r7) {
+    uint32_t Hl = perm(c.tblH1, c.tblH0, cnt_lo), Ll = perm(c.tblL1, c.tblL0, cnt_lo);
+    uint32_t Hh = perm(c.tblH1, c.tblH0, cnt_hi), Lh = perm(c.tblL1, c.tblL0, cnt_hi);
+    if (row_edge | l0 | r7) {
+        // entries 0..3 = degree 3, 4..6 = degree 2 (a corner: edge row and edge column)
+        const uint32_t il = cnt_lo + ((row_edge && l0) ? 0x00000004u : 0u), ih = cnt_hi + ((row_edge && r7) ? 0x04000000u : 0u);
+        const uint32_t ml = row_edge ? 0xFFFFFFFFu : (l0 ? 0x000000FFu : 0u), mh = row_edge ? 0xFFFFFFFFu : (r7 ? 0xFF000000u : 0u);
+        Hl = (Hl & ~ml) | (perm(c.t3H1, c.t3H0, il) & ml);
+        Ll = (Ll & ~ml) | (perm(c.t3L1, c.t3L0, il) & ml);
+        Hh = (Hh & ~mh) | (perm(c.t3H1, c.t3H0, ih) & mh);
+        Lh = (Lh & ~mh) | (perm(c.t3L1, c.t3L0, ih) & mh);
+    }
     u32x4 d;
     d.x = subsat16(w.x, perm(Hl, Ll, 0x05010400u));
     d.y = subsat16(w.y, perm(Hl, Ll, 0x07030602u));
@@ -315,7 +349,7 @@ static __device__ __forceinline__ uint64_t pack_flags(const u32x4& d) {
 }
 
 // P0 = column parity of the updated colour in row tr_lo (and 1-P0 in the row below it)
-template <int NO, int P0, bool EDGE>
+template <int NO, int P0, bool EDGE, bool OPEN>
 static __device__ __forceinline__ void sweep_pairs(const Rows2Ctx& c, const PhiloxKeys& K, int al, int oct, uint32_t cq, int RL) {
     // One byte offset into the source plane and one row counter are the only induction variables (kept opaque so
     // that the compiler does not re-derive them from a separate trip counter); everything else is an immediate.
@@ -354,21 +388,39 @@ static __device__ __forceinline__ void sweep_pairs(const Rows2Ctx& c, const Phil
         const uint32_t ml = C0l + C1l, mh = C0h + C1h;
         const uint32_t cnt0l = (uint32_t)R0 + ml + S0l, cnt0h = (uint32_t)(R0 >> 32) + mh + S0h;
         const uint32_t cnt1l = (uint32_t)R3 + ml + S1l, cnt1h = (uint32_t)(R3 >> 32) + mh + S1h;
-        u32x4 d0 = compare_octet(w0, cnt0l, cnt0h, c.tblH0, c.tblH1, c.tblL0, c.tblL1);
-        u32x4 d1 = compare_octet(w1, cnt1l, cnt1h, c.tblH0, c.tblH1, c.tblL0, c.tblL1);
+        u32x4 d0, d1;
+        uint32_t edge_a = 0, edge_b = 0;
+        if (OPEN) {
+            // row a updates the columns of parity P0, row b those of parity 1 - P0: the lattice's first column is site 0
+            // of octet 0 for parity 0, its last column site 7 of the last octet for parity 1
+            const bool ea = rga == 0 || rga == c.last_row, eb = rgb == 0 || rgb == c.last_row;
+            const bool la = !P0 && c.lft, ra = P0 && c.rgt, lb = P0 && c.lft, rb = !P0 && c.rgt;
+            d0 = compare_octet_open(w0, cnt0l, cnt0h, c, ea, la, ra);
+            d1 = compare_octet_open(w1, cnt1l, cnt1h, c, eb, lb, rb);
+            edge_a = (ea ? 1u : 0u) | (la ? 2u : 0u) | (ra ? 4u : 0u);
+            edge_b = (eb ? 1u : 0u) | (lb ? 2u : 0u) | (rb ? 4u : 0u);
+        } else {
+            d0 = compare_octet(w0, cnt0l, cnt0h, c.tblH0, c.tblH1, c.tblL0, c.tblL1);
+            d1 = compare_octet(w1, cnt1l, cnt1h, c.tblH0, c.tblH1, c.tblL0, c.tblL1);
+        }
         const uint32_t mn = minu16(minu16(minu16(d0.x, d0.y), minu16(d0.z, d0.w)), minu16(minu16(d1.x, d1.y), minu16(d1.z, d1.w)));
         if (__builtin_expect(((mn & 0xFFFFu) == 0) | ((mn >> 16) == 0), 0)) {
-            if (has_zero_field(d0)) d0 = resolve_ties(d0, w0, cnt0l, cnt0h, c.s_thr, cq, (uint32_t)rga, c.hs, c.tag_lo, c.k0, c.k1);
-            if (has_zero_field(d1)) d1 = resolve_ties(d1, w1, cnt1l, cnt1h, c.s_thr, cq, (uint32_t)rgb, c.hs, c.tag_lo, c.k0, c.k1);
+            if (has_zero_field(d0)) d0 = resolve_ties(d0, w0, cnt0l, cnt0h, c.s_thr, cq, (uint32_t)rga, c.hs, c.tag_lo, c.k0, c.k1, edge_a);
+            if (has_zero_field(d1)) d1 = resolve_ties(d1, w1, cnt1l, cnt1h, c.s_thr, cq, (uint32_t)rgb, c.hs, c.tag_lo, c.k0, c.k1, edge_b);
         }
         char* pd = const_cast<char*>(ps) + d_off;
-        *reinterpret_cast<uint64_t*>(pd) = pack_flags(d0);
-        *reinterpret_cast<uint64_t*>(pd + NO * 8) = pack_flags(d1);
+        uint64_t n0 = pack_flags(d0), n1 = pack_flags(d1);
+        if (OPEN) {  // what lies beyond the open edge stays empty (it is a neighbour of the edge sites in the next half-sweep)
+            if (c.col_out || rga < 0 || rga > c.last_row) n0 = 0;
+            if (c.col_out || rgb < 0 || rgb > c.last_row) n1 = 0;
+        }
+        *reinterpret_cast<uint64_t*>(pd) = n0;
+        *reinterpret_cast<uint64_t*>(pd + NO * 8) = n1;
     }
 }
 
 // one tile: HBM -> LDS planes, 2k half-sweeps, interior -> HBM (the other buffer)
-template <int HT, int WO, int THREADS>
+template <int HT, int WO, int THREADS, bool OPEN = false>
 static __device__ __forceinline__ void tile_body(const TiledParams& p, const int8_t* __restrict__ src, int8_t* __restrict__ dst,
                                                  const int k, const uint32_t sweep0, const int tx, const int ty, uint64_t* lds,
                                                  const PhiloxKeys& K) {
@@ -385,20 +437,24 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
     uint64_t* plane1 = plane0 + TR * NO;
     uint64_t* s_thr = plane1 + TR * NO + NO + 1;  // one spare row: the pair loop reads row idx + 2 NO of the last pair
     const int tid = threadIdx.x;
-    if (tid < 5) s_thr[tid] = p.thr[tid];
+    if (tid < 25) s_thr[tid] = p.thr[tid];
 
     const int q0 = tx * WO, r0 = p.r_begin + ty * H, Rb = r0 - 2 * k;
 
     // a thread owns one octet column (al = row lane, oct = column) in all three phases: no div/mod in any loop
     const int al = tid / NO, oct = tid - al * NO;
     int cqi = q0 - 1 + oct;
-    if (cqi < 0) cqi += p.nchunks;
-    if (cqi >= p.nchunks) cqi -= p.nchunks;
-    if (cqi >= p.nchunks) cqi -= p.nchunks;
+    // open lattice: octets outside the lattice hold no spins (flags 0); their (discarded) results still take a counter
+    const bool col_out = OPEN && (cqi < 0 || cqi >= p.nchunks);
+    if (!OPEN) {
+        if (cqi < 0) cqi += p.nchunks;
+        if (cqi >= p.nchunks) cqi -= p.nchunks;
+        if (cqi >= p.nchunks) cqi -= p.nchunks;
+    }
     const uint32_t cq = (uint32_t)cqi;
 
     if (!p.debug && al < RLMAX) {
-        const int8_t* col = src + 16 * (long long)cq;
+        const int8_t* col = src + 16 * (long long)(OPEN ? (cqi < 0 ? 0 : (cqi >= p.nchunks ? p.nchunks - 1 : cqi)) : cqi);
         // four rows per step, all four 16-byte loads in flight before the first is converted: the stage is one
         // HBM latency per step, so fewer, wider steps
         constexpr int LB = 4;
@@ -420,8 +476,12 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
                     // de-interleave the two colours, then +1 (0x01) -> 1, -1 (0xFF) -> 0: bit 1 of the byte, inverted
                     const uint32_t e0 = perm(v[b].y, v[b].x, 0x06040200u), e1 = perm(v[b].w, v[b].z, 0x06040200u);
                     const uint32_t o0 = perm(v[b].y, v[b].x, 0x07050301u), o1 = perm(v[b].w, v[b].z, 0x07050301u);
-                    const uint64_t ev = (uint64_t)(~(e0 >> 1) & 0x01010101u) | ((uint64_t)(~(e1 >> 1) & 0x01010101u) << 32);
-                    const uint64_t od = (uint64_t)(~(o0 >> 1) & 0x01010101u) | ((uint64_t)(~(o1 >> 1) & 0x01010101u) << 32);
+                    uint64_t ev = (uint64_t)(~(e0 >> 1) & 0x01010101u) | ((uint64_t)(~(e1 >> 1) & 0x01010101u) << 32);
+                    uint64_t od = (uint64_t)(~(o0 >> 1) & 0x01010101u) | ((uint64_t)(~(o1 >> 1) & 0x01010101u) << 32);
+                    if (OPEN) {
+                        const long long grow = p.row0 + Rb + tr;
+                        if (col_out || grow < 0 || grow >= p.total_rows) ev = od = 0;  // beyond the open edge: nothing there
+                    }
                     const int idx = tr * NO + oct;
                     const int gpar = (int)((p.row0 + Rb + tr) & 1);  // colour of the even columns of this row
                     (gpar ? plane1 : plane0)[idx] = ev;
@@ -431,9 +491,12 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
         }
     }
 
-    long long rg0 = (p.row0 + Rb) % p.total_rows;
-    if (rg0 < 0) rg0 += p.total_rows;
-    const bool edge = (rg0 + TR > p.total_rows);
+    long long rg0 = p.row0 + Rb;
+    if (!OPEN) {
+        rg0 %= p.total_rows;
+        if (rg0 < 0) rg0 += p.total_rows;
+    }
+    const bool edge = !OPEN && (rg0 + TR > p.total_rows);  // open lattices do not wrap: rows beyond the edge are discarded
 
     Rows2Ctx c;
     c.s_thr = s_thr;
@@ -441,6 +504,11 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
     c.tag_hi = p.tag_hi; c.tag_lo = p.tag_lo; c.k0 = p.k0; c.k1 = p.k1;
     // the threshold byte tables live in VGPRs: v_perm_b32 may read only one SGPR, so SGPR tables cost a v_mov per use
     c.tblH0 = p.tblH0; c.tblH1 = p.tblH1; c.tblL0 = p.tblL0; c.tblL1 = p.tblL1;
+    c.t3H0 = p.t3H0; c.t3H1 = p.t3H1; c.t3L0 = p.t3L0; c.t3L1 = p.t3L1;
+    c.last_row = (int)p.total_rows - 1;
+    c.lft = OPEN && cqi == 0;
+    c.rgt = OPEN && cqi == p.nchunks - 1;
+    c.col_out = col_out;
     asm volatile("v_mov_b32 %0, %1" : "=v"(c.tblH0) : "s"(p.tblH0));
     asm volatile("v_mov_b32 %0, %1" : "=v"(c.tblH1) : "s"(p.tblH1));
     asm volatile("v_mov_b32 %0, %1" : "=v"(c.tblL0) : "s"(p.tblL0));
@@ -455,16 +523,19 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
         c.tr_lo = 1 + hsi;
         c.npairs = (TR - 2 - 2 * hsi) / 2;  // rows [1 + hsi, TR - 2 - hsi] in pairs (TR is even)
         int rgf = (int)rg0 + c.tr_lo;
-        if (rgf >= c.total_rows) rgf -= c.total_rows;
+        if (!OPEN && rgf >= c.total_rows) rgf -= c.total_rows;
         c.rgf = rgf;
         const int par0 = (int)((p.row0 + Rb + c.tr_lo + kappa) & 1);
         if (al < RL) {
-            if (edge) {
-                if (par0) sweep_pairs<NO, 1, true>(c, K, al, oct, cq, RL);
-                else sweep_pairs<NO, 0, true>(c, K, al, oct, cq, RL);
+            if (OPEN) {
+                if (par0) sweep_pairs<NO, 1, false, true>(c, K, al, oct, cq, RL);
+                else sweep_pairs<NO, 0, false, true>(c, K, al, oct, cq, RL);
+            } else if (edge) {
+                if (par0) sweep_pairs<NO, 1, true, false>(c, K, al, oct, cq, RL);
+                else sweep_pairs<NO, 0, true, false>(c, K, al, oct, cq, RL);
             } else {
-                if (par0) sweep_pairs<NO, 1, false>(c, K, al, oct, cq, RL);
-                else sweep_pairs<NO, 0, false>(c, K, al, oct, cq, RL);
+                if (par0) sweep_pairs<NO, 1, false, false>(c, K, al, oct, cq, RL);
+                else sweep_pairs<NO, 0, false, false>(c, K, al, oct, cq, RL);
             }
         }
     }
@@ -492,12 +563,12 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
     }
 }
 
-template <int H, int WO, int THREADS, int MINW = 1>
+template <int H, int WO, int THREADS, int MINW = 1, bool OPEN = false>
 __global__ __launch_bounds__(THREADS, MINW) void k1_tiled2(TiledParams p) {
     extern __shared__ uint64_t lds[];
     const PhiloxKeys K = make_keys(p.k0, p.k1);
-    tile_body<H, WO, THREADS>(p, p.src, p.dst, p.k, p.sweep0, blockIdx.x % p.tiles_x,
-                              p.ty_first + (blockIdx.x / p.tiles_x) * p.ty_stride, lds, K);
+    tile_body<H, WO, THREADS, OPEN>(p, p.src, p.dst, p.k, p.sweep0, blockIdx.x % p.tiles_x,
+                                    p.ty_first + (blockIdx.x / p.tiles_x) * p.ty_stride, lds, K);
 }
 
 // ------------------------------------------------------------------ persistent multi-generation kernel
@@ -582,6 +653,7 @@ struct TileVariant {
     int H, WO, threads;
     void (*kernel)(TiledParams);
     void (*persist)(PersistParams);  // multi-generation form (nullptr: not built for this shape)
+    void (*open)(TiledParams);       // open-boundary form (nullptr: not built for this shape)
 };
 // tile shapes compiled in; TSU_TILE_VARIANT (env, development aid) or tsu_ising2d_set_kernel picks one
 const TileVariant kVariants[] = {
@@ -591,10 +663,10 @@ const TileVariant kVariants[] = {
     {64, 64, 512, k1_tiled<64, 64, 512>},
     {32, 32, 256, k1_tiled<32, 32, 256>},
     {128, 32, 1024, k1_tiled<128, 32, 1024>},
-    {64, 32, 512, k1_tiled2<64, 32, 512>, k1_persist<64, 32, 512>},    // 6: v2 inner loop (row pairs, VGPR keys)
+    {64, 32, 512, k1_tiled2<64, 32, 512>, k1_persist<64, 32, 512>, k1_tiled2<64, 32, 512, 1, true>},    // 6: v2 inner loop (row pairs, VGPR keys)
     {64, 32, 256, k1_tiled2<64, 32, 256>},    // 7
-    {128, 32, 512, k1_tiled2<128, 32, 512>, k1_persist<128, 32, 512>},  // 8
-    {128, 32, 1024, k1_tiled2<128, 32, 1024>, k1_persist<128, 32, 1024>},// 9
+    {128, 32, 512, k1_tiled2<128, 32, 512>, k1_persist<128, 32, 512>, k1_tiled2<128, 32, 512, 1, true>},  // 8
+    {128, 32, 1024, k1_tiled2<128, 32, 1024>, k1_persist<128, 32, 1024>, k1_tiled2<128, 32, 1024, 1, true>},// 9
     {64, 32, 1024, k1_tiled2<64, 32, 1024>},  // 10
     {64, 32, 576, k1_tiled2<64, 32, 576>},    // 11
     {128, 32, 640, k1_tiled2<128, 32, 640>},  // 12
@@ -639,10 +711,11 @@ int pick_variant(const tsu_ising2d* L) {
 }  // namespace
 
 int tsu_ising2d_tiled_supported(const tsu_ising2d* L) {
-    if (!L->periodic) return 0;                               // open edges: generic kernel
     if (L->cols % 16 != 0) return 0;                          // octets must align with 16-byte chunks
     if (L->cols / 16 < kVariants[0].WO + 2) return 0;         // tile wider than the lattice: generic kernel
-    if (!L->wrap_rows && L->ghost < 2) return 0;
+    const bool open_whole = !L->periodic && L->ghost == 0 && L->total_rows == L->rows;  // beyond its edges: nothing
+    if (!L->periodic && !kVariants[pick_variant(L)].open) return 0;  // open edges need the OPEN form of the kernel
+    if (!L->wrap_rows && !open_whole && L->ghost < 2) return 0;
     if (L->total_rows < kVariants[0].H + 4 * KMAX) return 0;  // single wrap of the global row index
     return 1;
 }
@@ -664,7 +737,9 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
     // sweeps per launch: more sweeps amortise the tile load/store and the launch gap, fewer carry less halo work
     int kmax = L->sweeps_per_launch > 0 ? L->sweeps_per_launch : ((long long)L->rows * L->cols <= 4096ll * 4096ll ? 8 : 5);
     if (kmax > KMAX) kmax = KMAX;
-    if (!L->wrap_rows) {
+    const bool open_whole = !L->periodic && L->ghost == 0 && L->total_rows == L->rows;
+    const bool slab = !L->wrap_rows && !open_whole;
+    if (slab) {
         // A slab may sweep ghost/2 times between two ghost refreshes.  When that takes several launches, every launch
         // but the last also computes the ghost rows the following launches will read (2 rows per remaining sweep on
         // each side, from input that is still exact there), instead of waiting for the neighbours.
@@ -697,22 +772,30 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
     p.k1 = (uint32_t)(seed >> 32);
     p.tag_hi = TSU_TAG_ISING_HI | (replica << 8);
     p.tag_lo = TSU_TAG_ISING_LO | (replica << 8);
-    uint32_t t16[5];
-    for (int c = 0; c < 5; ++c) {
-        uint64_t thr = L->table[4 * 5 + c];
-        p.thr[c] = thr;
+    for (int c = 0; c < 25; ++c) p.thr[c] = L->table[c];
+    p.open = L->periodic ? 0 : 1;
+    auto top16 = [](uint64_t thr) {
         uint32_t thi = (uint32_t)(thr >> 16);
         if (thi > 65535u) thi = 65535u;
-        t16[c] = thi ^ 0x8000u;
-    }
+        return thi ^ 0x8000u;
+    };
+    uint32_t t16[5], t3[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int c = 0; c < 5; ++c) t16[c] = top16(L->table[4 * 5 + c]);
+    for (int c = 0; c < 4; ++c) t3[c] = top16(L->table[3 * 5 + c]);      // degree 3: an edge
+    for (int c = 0; c < 3; ++c) t3[4 + c] = top16(L->table[2 * 5 + c]);  // degree 2: a corner
+    p.t3L0 = (t3[0] & 0xFF) | ((t3[1] & 0xFF) << 8) | ((t3[2] & 0xFF) << 16) | ((t3[3] & 0xFF) << 24);
+    p.t3L1 = (t3[4] & 0xFF) | ((t3[5] & 0xFF) << 8) | ((t3[6] & 0xFF) << 16);
+    p.t3H0 = (t3[0] >> 8) | ((t3[1] >> 8) << 8) | ((t3[2] >> 8) << 16) | ((t3[3] >> 8) << 24);
+    p.t3H1 = (t3[4] >> 8) | ((t3[5] >> 8) << 8) | ((t3[6] >> 8) << 16);
     p.tblL0 = (t16[0] & 0xFF) | ((t16[1] & 0xFF) << 8) | ((t16[2] & 0xFF) << 16) | ((t16[3] & 0xFF) << 24);
     p.tblL1 = (t16[4] & 0xFF);
     p.tblH0 = (t16[0] >> 8) | ((t16[1] >> 8) << 8) | ((t16[2] >> 8) << 16) | ((t16[3] >> 8) << 24);
     p.tblH1 = (t16[4] >> 8);
-    static bool attr_set[kNumVariants] = {};
-    if (!attr_set[&tv - kVariants]) {
-        TSU_HIP_TRY(ctx, hipFuncSetAttribute((const void*)tv.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set[&tv - kVariants] = true;
+    void (*const kern)(TiledParams) = L->periodic ? tv.kernel : tv.open;
+    static bool attr_set[kNumVariants][2] = {};
+    if (!attr_set[&tv - kVariants][p.open]) {
+        TSU_HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[&tv - kVariants][p.open] = true;
     }
     static int use_persist = -1;
     if (use_persist < 0) {
@@ -721,7 +804,7 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
         const char* e = getenv("TSU_K1_PERSIST");
         use_persist = e ? atoi(e) : 0;
     }
-    if (use_persist && tv.persist && L->wrap_rows && part == TSU_PART_ALL && n_sweeps > kmax && !p.debug) {
+    if (use_persist && tv.persist && L->periodic && L->wrap_rows && part == TSU_PART_ALL && n_sweeps > kmax && !p.debug) {
         // ---- one persistent launch for all generations (whole periodic lattice on this GPU)
         const int vi = (int)(&tv - kVariants);
         const int ntiles = p.tiles_x * tiles_y;
@@ -755,7 +838,7 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
         P.done = L->d_sync + 1;
         P.err = d_err;
         const int TRmax = TILE_H + 4 * kmax;
-        const size_t lds_bytes = ((size_t)2 * TRmax * TILE_NO + TILE_NO + 2 + 5) * sizeof(uint64_t);
+        const size_t lds_bytes = ((size_t)2 * TRmax * TILE_NO + TILE_NO + 2 + 25) * sizeof(uint64_t);
         static bool pattr[kNumVariants] = {};
         static int resident[kNumVariants] = {};
         if (!pattr[vi]) {
@@ -784,8 +867,8 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
         p.src = L->alloc[L->cur] + (size_t)L->ghost * L->pitch;
         p.dst = L->alloc[L->cur ^ 1] + (size_t)L->ghost * L->pitch;
         int TR = TILE_H + 4 * k;
-        size_t lds_bytes = ((size_t)2 * TR * TILE_NO + TILE_NO + 2 + 5) * sizeof(uint64_t);
-        if (!L->wrap_rows && part == TSU_PART_ALL) {
+        size_t lds_bytes = ((size_t)2 * TR * TILE_NO + TILE_NO + 2 + 25) * sizeof(uint64_t);
+        if (slab && part == TSU_PART_ALL) {
             const int ext = 2 * (n_sweeps - done - k);  // rows of ghost the remaining sweeps of this refresh period need
             p.r_begin = -ext;
             p.r_end = L->rows + ext;
@@ -795,12 +878,12 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
             int th = (p.r_end - p.r_begin + base_ty - 1) / base_ty;
             th += th & 1;
             const size_t lds_share = (tv.threads >= 1024 ? 160u : 80u) * 1024u;
-            const size_t need = ((size_t)2 * (th + 4 * k) * TILE_NO + TILE_NO + 2 + 5) * sizeof(uint64_t);
+            const size_t need = ((size_t)2 * (th + 4 * k) * TILE_NO + TILE_NO + 2 + 25) * sizeof(uint64_t);
             if (need > lds_share || th < TILE_H) th = TILE_H;
             p.tile_h = th;
             tiles_y = (p.r_end - p.r_begin + th - 1) / th;
             TR = th + 4 * k;
-            lds_bytes = ((size_t)2 * TR * TILE_NO + TILE_NO + 2 + 5) * sizeof(uint64_t);
+            lds_bytes = ((size_t)2 * TR * TILE_NO + TILE_NO + 2 + 25) * sizeof(uint64_t);
         }
         // tile rows 0 and tiles_y-1 read ghost rows (2k <= H); the others only read owned rows
         int n_ty = tiles_y;
@@ -814,7 +897,7 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
             n_ty = 2;
         }
         if (n_ty > 0)
-            hipLaunchKernelGGL(tv.kernel, dim3((unsigned)(p.tiles_x * n_ty)), dim3((unsigned)tv.threads), lds_bytes, ctx->stream, p);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_x * n_ty)), dim3((unsigned)tv.threads), lds_bytes, ctx->stream, p);
         if (part != TSU_PART_INTERIOR) L->cur ^= 1;  // INTERIOR does not publish; BOUNDARY (or ALL) does
         done += k;
     }
