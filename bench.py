@@ -144,8 +144,8 @@ def time_dense(hip, ctx, n=16384):
     d.sweep(1.0, 2, seed=1, sweep0=0)
     ctx.synchronize()
     ctx.timer_begin()
-    d.sweep(1.0, 8, seed=1, sweep0=2)
-    ms = ctx.timer_end() / 8
+    d.sweep(1.0, 16, seed=1, sweep0=2)  # one call: the fields are handed from sweep to sweep inside it
+    ms = ctx.timer_end() / 16
     d.close()
     return {"N": n, "dtype": "f32", "ms_per_sweep": ms, "spin_updates_per_s": n / (ms * 1e-3),
             "J_stream_GBps": n * n * 4 / (ms * 1e-3) / 1e9}

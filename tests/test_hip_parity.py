@@ -271,6 +271,10 @@ def test_dense_superblocks_match_oracle(hip, n, dtype, T, sym):
     d.sweep(T, 2, seed=77, sweep0=8)
     want = ora.dense_sweep_philox(want, J, b, T, 2, 77, sweep0=8)
     np.testing.assert_array_equal(d.get_state(), want)
+    if n == 2051:  # many sweeps in one call: fields handed from sweep to sweep, recomputed every 64th
+        d.set_state(st)
+        d.sweep(T, 70, seed=78, sweep0=0)
+        np.testing.assert_array_equal(d.get_state(), ora.dense_sweep_philox(st, J, b, T, 70, 78, sweep0=0))
     # replayed uniforms take the same path
     u = rng.random(size=(2, n))
     d.set_state(st)

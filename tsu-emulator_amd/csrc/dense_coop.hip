@@ -9,7 +9,8 @@
 //     previous iteration (a list of tens) are applied to the rows below them;
 //   * the streaming passes (field, triangular pass, strip update of the later rows) read J with 16-byte loads,
 //     eight in flight per lane.
-// Per sweep: field pass N^2 + strips N^2/2 + triangular passes N*SB_SIZE/2 elements of J from HBM.
+// Per sweep: strips N^2 (every row times every superblock's columns: J exactly once) + triangular passes
+// N*SB_SIZE/2 elements of J from HBM; the first sweep of a call and every 64th add a field pass of N^2.
 //
 // Phases (B = grid barrier):
 //   A   f_i = b_i + J[i,:].s, logit_i = logit(u_i(sweep)); d0_i = decide(f_i) - s_i for the first superblock      B
@@ -22,6 +23,7 @@
 
 #define CO_THREADS 1024
 #define CO_MAX_N 65536         // bytes of LDS for the staged state vector (phase A)
+#define CO_REFRESH 64          // sweeps between two full recomputations of the fields (bounds floating-point drift)
 #define CO_SLOTS 64            // iterations recorded per superblock; more than that = not converged (never seen)
 #define CO_TIMEOUT 400000000ll // wall_clock64 ticks (100 MHz): 4 s
 
@@ -253,10 +255,15 @@ __global__ __launch_bounds__(CO_THREADS) void k2_coop(CoopParams P) {
     for (int sw = 0; sw < P.n_sweeps; ++sw) {
         const uint32_t t = P.sweep0 + (uint32_t)sw;
         const double* uni = P.uniforms ? P.uniforms + (size_t)sw * n : nullptr;
-        // ---- A: field, logits, first guesses of superblock 0
-        stage_weights(s, 0, n, wl);
+        // ---- A: field, logits, first guesses of superblock 0 -- on the first sweep of a call and every CO_REFRESH
+        // sweeps; in between, phase C keeps every field current (f += J[:, sb] . flips for ALL rows), so that J is
+        // streamed once per sweep (the strips) instead of once for the fields plus half again for the strips
+        const bool fresh = (sw % CO_REFRESH) == 0;
+        const bool next_incremental = sw + 1 < P.n_sweeps && ((sw + 1) % CO_REFRESH) != 0;
+        const double* uni_next = P.uniforms ? P.uniforms + (size_t)(sw + 1) * n : nullptr;
+        if (fresh) stage_weights(s, 0, n, wl);
         __syncthreads();
-        for (int i = gw; i < n; i += NW) {
+        for (int i = gw; fresh && i < n; i += NW) {
             const double acc = wave_dot<TJ, VEC>(J + (size_t)i * n, wl, 0, 0, n, lane);
             if (lane == 0) {
                 const double F = acc + (P.bias ? P.bias[i] : 0.0);
@@ -267,8 +274,10 @@ __global__ __launch_bounds__(CO_THREADS) void k2_coop(CoopParams P) {
                     st(P.d0 + i, (int8_t)(co_decide(F, lg, T, invT, (uint32_t)i, uni, t, P.tag, P.k0, P.k1) - (int)wl[i]));
             }
         }
-        if (!grid_barrier(B)) return;
-        TL_MARK(0);
+        if (fresh) {
+            if (!grid_barrier(B)) return;
+            TL_MARK(0);
+        }
         int* counts = P.counts + (size_t)sw * nsb * CO_SLOTS;
         for (int p0 = 0; p0 < n; p0 += SB_SIZE, counts += CO_SLOTS) {
             const int cnt = n - p0 < SB_SIZE ? n - p0 : SB_SIZE;
@@ -336,19 +345,30 @@ __global__ __launch_bounds__(CO_THREADS) void k2_coop(CoopParams P) {
                 TL_MARK(2);
             }
             if (k > worst) worst = k;
-            // ---- C: commit the superblock, add its flips to every later field, first guesses of the next superblock
+            // ---- C: commit the superblock; add its flips to the fields -- of the later rows, or of all rows when the
+            // next sweep does not recompute them; first guesses of the next superblock; after the last superblock of a
+            // sweep that hands its fields on: next sweep's logits and the first guesses of its superblock 0
             stage_weights(P.d1, p0, pe, wl);
             __syncthreads();
             for (int i = p0 + gtid; i < pe; i += NT) st(s_new + i, (int8_t)(ld(s + i) + wl[i - p0]));
-            for (int r = pe + gw; r < n; r += NW) {
-                const bool next_sb = r < pe + SB_SIZE;
+            const bool hand_on = next_incremental && pe == n;
+            for (int r = (next_incremental ? 0 : pe) + gw; r < n; r += NW) {
+                const bool next_sb = r >= pe && r < pe + SB_SIZE;
                 const double fr = ld(P.f + r), lgr = next_sb ? ld(P.lg + r) : 0.0;
                 const int sr = next_sb ? (int)ld(s + r) : 0;
+                int snr = 0;
+                if (hand_on && r < SB_SIZE) snr = r >= p0 ? (int)ld(s + r) + (int)wl[r - p0] : (int)ld(s_new + r);
                 const double acc = wave_dot<TJ, VEC>(J + (size_t)r * n, wl, p0, p0, pe, lane);
                 if (lane == 0) {
                     const double F = fr + acc;
                     st(P.f + r, F);
                     if (next_sb) st(P.d0 + r, (int8_t)(co_decide(F, lgr, T, invT, (uint32_t)r, uni, t, P.tag, P.k0, P.k1) - sr));
+                    if (hand_on) {
+                        const double lgn = co_logit((uint32_t)r, uni_next, t + 1, P.tag, P.k0, P.k1);
+                        st(P.lg + r, lgn);
+                        if (r < SB_SIZE)
+                            st(P.d0 + r, (int8_t)(co_decide(F, lgn, T, invT, (uint32_t)r, uni_next, t + 1, P.tag, P.k0, P.k1) - snr));
+                    }
                 }
             }
             if (!grid_barrier(B)) return;
