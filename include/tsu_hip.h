@@ -45,6 +45,7 @@ extern "C" {
 #define TSU_KERNEL_AUTO 0    /* pick the fastest kernel that supports the lattice */
 #define TSU_KERNEL_GENERIC 1 /* one colour per launch, global memory, any shape / boundary */
 #define TSU_KERNEL_TILED 2   /* LDS-staged halo tiles, several sweeps per launch */
+#define TSU_KERNEL_SMALL 3   /* whole (small) lattice resident in one workgroup's LDS, all sweeps in one launch */
 
 typedef struct tsu_ctx tsu_ctx;
 typedef struct tsu_ising2d tsu_ising2d;

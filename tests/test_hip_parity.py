@@ -39,14 +39,18 @@ LATTICES = [(8, 8, True), (32, 32, True), (64, 64, True), (4, 4, True), (6, 20, 
             (5, 16, False), (16, 17, False), (64, 1024, True), (12, 2050, True)]
 
 
-@pytest.mark.parametrize("kernel", ["generic", "auto"])
+@pytest.mark.parametrize("kernel", ["generic", "auto", "small"])
 @pytest.mark.parametrize("rows,cols,periodic", LATTICES)
 def test_ising2d_sweep_bit_exact(hip, rows, cols, periodic, kernel):
     seed = 1000 + rows * 31 + cols
     for (J, h, T, mode) in [(1.0, 0.0, 2.269185, hip.MODE_PHYSICAL), (-0.7, 0.3, 1.1, hip.MODE_COMPAT)]:
         table = ora.ising2d_thresholds(J, h, T, mode)
         lat = hip.Lattice(rows, cols, periodic)
-        lat.set_kernel(hip.KERNEL_GENERIC if kernel == "generic" else hip.KERNEL_AUTO)
+        if kernel == "small" and rows * ((cols + 15) // 16) > 1024:
+            with pytest.raises(hip.UnsupportedError):
+                lat.set_kernel(hip.KERNEL_SMALL)
+            return
+        lat.set_kernel({"generic": hip.KERNEL_GENERIC, "auto": hip.KERNEL_AUTO, "small": hip.KERNEL_SMALL}[kernel])
         lat.randomize(seed)
         s0 = lat.get_spins()
         np.testing.assert_array_equal(s0, ora.ising2d_randomize(rows, cols, seed))

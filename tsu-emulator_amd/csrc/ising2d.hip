@@ -46,34 +46,13 @@ static __device__ __forceinline__ bool row_exists(const K1Params& p, int r) {
     return r >= -p.top_rows && r < p.rows + p.bot_rows;
 }
 
-// ------------------------------------------------------------------ generic kernel: one colour per launch
-// thread = one octet = 16 consecutive columns of one row (8 sites of the launch colour).
-__global__ __launch_bounds__(256) void k1_generic(K1Params p, K1Table tbl, int colour) {
-    __shared__ uint64_t s_tbl[25];
-    int tid = threadIdx.y * 64 + threadIdx.x;
-    if (tid < 25) s_tbl[tid] = tbl.t[tid];
-    __syncthreads();
-
-    int q = blockIdx.x * 64 + threadIdx.x;          // octet / 16-byte chunk index
-    int r = p.r_lo + blockIdx.y * 4 + threadIdx.y;  // local row
-    int nchunks = (p.cols + 15) >> 4;
-    if (q >= nchunks || r >= p.r_hi) return;
-
-    long long gr = global_row(p, r);
-    int par = (int)((gr + colour) & 1);  // column parity of this colour in this row
-    const int8_t* row = p.base + (long long)r * p.pitch;
-
-    // vertical neighbour rows: buffer row, wrapped row, or absent (zeros)
-    const int8_t* up_row = nullptr;
-    const int8_t* dn_row = nullptr;
-    if (p.wrap_rows) {
-        up_row = p.base + (long long)(r == 0 ? p.rows - 1 : r - 1) * p.pitch;
-        dn_row = p.base + (long long)(r == p.rows - 1 ? 0 : r + 1) * p.pitch;
-    } else {
-        if (row_exists(p, r - 1)) up_row = row - p.pitch;
-        if (row_exists(p, r + 1)) dn_row = row + p.pitch;
-    }
-
+// ------------------------------------------------------------------ one octet of one colour
+// 16 consecutive columns of one row (8 sites of the half-sweep's colour): neighbour bytes, degree and up-count per
+// site, one Philox block, thresholds from s_tbl, masked 16-byte store.  `row`, `up_row`, `dn_row` (NULL = absent) and
+// `out_chunk` may point into global memory (k1_generic) or LDS (k1_small): the row layout is the same.
+static __device__ __forceinline__ void k1_update_octet(const K1Params& p, const uint64_t* s_tbl, const int8_t* row,
+                                                       const int8_t* up_row, const int8_t* dn_row, int8_t* out_chunk, int q,
+                                                       long long gr, int par, int nchunks, uint32_t hs) {
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
     uint4 cv = *reinterpret_cast<const uint4*>(row + 16 * q);
     uint4 uv = up_row ? *reinterpret_cast<const uint4*>(up_row + 16 * q) : zero4;
@@ -110,7 +89,7 @@ __global__ __launch_bounds__(256) void k1_generic(K1Params p, K1Table tbl, int c
         D0 = (dlo >> 8) | (dhi << 56); D1 = dhi >> 8;
     }
 
-    u32x4 w = tsu_philox((uint32_t)q, (uint32_t)gr, p.hs, p.tag_hi, p.k0, p.k1);
+    u32x4 w = tsu_philox((uint32_t)q, (uint32_t)gr, hs, p.tag_hi, p.k0, p.k1);
     uint32_t wv[4] = {w.x, w.y, w.z, w.w};
     bool have_lo = false;
     uint32_t lv[4] = {0, 0, 0, 0};
@@ -134,7 +113,7 @@ __global__ __launch_bounds__(256) void k1_generic(K1Params p, K1Table tbl, int c
         bool accept = hi < thi;
         if (hi == thi) {  // tie on the top 16 bits: evaluate the low half (rare)
             if (!have_lo) {
-                u32x4 l = tsu_philox((uint32_t)q, (uint32_t)gr, p.hs, p.tag_lo, p.k0, p.k1);
+                u32x4 l = tsu_philox((uint32_t)q, (uint32_t)gr, hs, p.tag_lo, p.k0, p.k1);
                 lv[0] = l.x; lv[1] = l.y; lv[2] = l.z; lv[3] = l.w;
                 have_lo = true;
             }
@@ -154,7 +133,74 @@ __global__ __launch_bounds__(256) void k1_generic(K1Params p, K1Table tbl, int c
     clo = (clo & ~M0) | (N0 & M0);
     chi = (chi & ~M1) | (N1 & M1);
     uint4 ov = make_uint4((uint32_t)clo, (uint32_t)(clo >> 32), (uint32_t)chi, (uint32_t)(chi >> 32));
-    *reinterpret_cast<uint4*>(p.out + (long long)r * p.pitch + 16 * q) = ov;
+    *reinterpret_cast<uint4*>(out_chunk) = ov;
+}
+
+
+// ------------------------------------------------------------------ generic kernel: one colour per launch
+// thread = one octet = 16 consecutive columns of one row (8 sites of the launch colour).
+__global__ __launch_bounds__(256) void k1_generic(K1Params p, K1Table tbl, int colour) {
+    __shared__ uint64_t s_tbl[25];
+    int tid = threadIdx.y * 64 + threadIdx.x;
+    if (tid < 25) s_tbl[tid] = tbl.t[tid];
+    __syncthreads();
+
+    int q = blockIdx.x * 64 + threadIdx.x;          // octet / 16-byte chunk index
+    int r = p.r_lo + blockIdx.y * 4 + threadIdx.y;  // local row
+    int nchunks = (p.cols + 15) >> 4;
+    if (q >= nchunks || r >= p.r_hi) return;
+
+    long long gr = global_row(p, r);
+    int par = (int)((gr + colour) & 1);  // column parity of this colour in this row
+    const int8_t* row = p.base + (long long)r * p.pitch;
+
+    // vertical neighbour rows: buffer row, wrapped row, or absent (zeros)
+    const int8_t* up_row = nullptr;
+    const int8_t* dn_row = nullptr;
+    if (p.wrap_rows) {
+        up_row = p.base + (long long)(r == 0 ? p.rows - 1 : r - 1) * p.pitch;
+        dn_row = p.base + (long long)(r == p.rows - 1 ? 0 : r + 1) * p.pitch;
+    } else {
+        if (row_exists(p, r - 1)) up_row = row - p.pitch;
+        if (row_exists(p, r + 1)) dn_row = row + p.pitch;
+    }
+    k1_update_octet(p, s_tbl, row, up_row, dn_row, p.out + (long long)r * p.pitch + 16 * q, q, gr, par, nchunks, p.hs);
+}
+
+// ------------------------------------------------------------------ small lattices: one workgroup, one launch
+// The whole lattice (not a slab) lives in LDS with the HBM row layout; all n_sweeps run inside one launch with one
+// workgroup barrier per half-sweep (in place: a half-sweep only writes its own colour, which no site of that colour
+// reads).  Same octet update, same Philox counters, hence the same results as k1_generic -- without two launches per
+// sweep, which is all a 32 x 32 lattice (BASELINE configs[0]) costs there.
+__global__ __launch_bounds__(1024) void k1_small(K1Params p, K1Table tbl, uint32_t sweep0, int n_sweeps) {
+    extern __shared__ int8_t s_lat[];
+    __shared__ uint64_t s_tbl[25];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int nchunks = (p.cols + 15) >> 4;
+    const int lp = 16 * nchunks;  // LDS row pitch: whole chunks, pad bytes 0 like the HBM rows
+    if (tid < 25) s_tbl[tid] = tbl.t[tid];
+    for (int t = tid; t < p.rows * nchunks; t += nt) {
+        const int r = t / nchunks, q = t - r * nchunks;
+        *reinterpret_cast<uint4*>(s_lat + r * lp + 16 * q) = *reinterpret_cast<const uint4*>(p.base + (long long)r * p.pitch + 16 * q);
+    }
+    __syncthreads();
+    for (int hsi = 0; hsi < 2 * n_sweeps; ++hsi) {
+        const int colour = hsi & 1;
+        const uint32_t hs = 2u * (sweep0 + (uint32_t)(hsi >> 1)) + (uint32_t)colour;
+        for (int t = tid; t < p.rows * nchunks; t += nt) {
+            const int r = t / nchunks, q = t - r * nchunks;
+            const int par = (r + colour) & 1;
+            int8_t* row = s_lat + r * lp;
+            const int8_t* up_row = r > 0 ? row - lp : (p.periodic ? s_lat + (p.rows - 1) * lp : nullptr);
+            const int8_t* dn_row = r < p.rows - 1 ? row + lp : (p.periodic ? s_lat : nullptr);
+            k1_update_octet(p, s_tbl, row, up_row, dn_row, row + 16 * q, q, (long long)r, par, nchunks, hs);
+        }
+        __syncthreads();
+    }
+    for (int t = tid; t < p.rows * nchunks; t += nt) {
+        const int r = t / nchunks, q = t - r * nchunks;
+        *reinterpret_cast<uint4*>(p.out + (long long)r * p.pitch + 16 * q) = *reinterpret_cast<const uint4*>(s_lat + r * lp + 16 * q);
+    }
 }
 
 // ------------------------------------------------------------------ K4: sum of spins, sum over bonds
@@ -280,6 +326,14 @@ static K1Params make_params(const tsu_ising2d* L, int8_t* buf) {
     }
     p.k0 = p.k1 = p.hs = p.tag_hi = p.tag_lo = 0;
     return p;
+}
+
+// k1_small: a whole lattice (not a slab) with at most one octet per thread of one workgroup (measured: 32 x 32 3.2 us
+// per sweep against 11 us for two generic launches; at 256 x 256 the whole chip wins: 8 us against 30 us)
+static bool small_supported(const tsu_ising2d* L) {
+    if (L->ghost != 0 || L->total_rows != L->rows || L->row0 != 0) return false;
+    const long long nchunks = (L->cols + 15) >> 4, tasks = (long long)L->rows * nchunks;
+    return tasks <= 1024;
 }
 
 static dim3 grid_for(const tsu_ising2d* L, int nrows) {
@@ -464,10 +518,12 @@ int tsu_ising2d_set_model(tsu_ising2d* L, double J, double h, double T, int mode
 
 int tsu_ising2d_set_kernel(tsu_ising2d* L, int kernel, int sweeps_per_launch) {
     if (!L) return TSU_E_INVALID;
-    TSU_REQUIRE(L->ctx, kernel >= TSU_KERNEL_AUTO && kernel <= TSU_KERNEL_TILED, "ising2d_set_kernel: bad kernel %d", kernel);
+    TSU_REQUIRE(L->ctx, kernel >= TSU_KERNEL_AUTO && kernel <= TSU_KERNEL_SMALL, "ising2d_set_kernel: bad kernel %d", kernel);
     TSU_REQUIRE(L->ctx, sweeps_per_launch >= 0 && sweeps_per_launch <= 16, "ising2d_set_kernel: sweeps_per_launch in [0,16]");
     if (kernel == TSU_KERNEL_TILED && !tsu_ising2d_tiled_supported(L))
         return tsu_fail(L->ctx, TSU_E_UNSUPPORTED, "ising2d_set_kernel: tiled kernel does not support this lattice");
+    if (kernel == TSU_KERNEL_SMALL && !small_supported(L))
+        return tsu_fail(L->ctx, TSU_E_UNSUPPORTED, "ising2d_set_kernel: the one-workgroup kernel takes whole lattices of at most 1024 octets (rows x ceil(cols/16))");
     L->kernel = kernel;
     L->sweeps_per_launch = sweeps_per_launch;
     return TSU_OK;
@@ -488,10 +544,31 @@ int tsu_ising2d_sweep_part(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_t
                 "ising2d_sweep: %d sweeps need %d ghost rows, slab has %d", n_sweeps, 2 * n_sweeps, L->ghost);
     if (n_sweeps == 0) return TSU_OK;
     if (L->timing) TSU_HIP_TRY(ctx, hipEventRecord(L->ev0, ctx->stream));
-    int use_tiled = (L->kernel == TSU_KERNEL_TILED) || (L->kernel == TSU_KERNEL_AUTO && tsu_ising2d_tiled_supported(L));
+    // AUTO: a lattice that fits one workgroup's LDS runs all its sweeps in one launch; larger ones take the tiled
+    // kernel where it applies, the generic one otherwise
+    const int use_small = part == TSU_PART_ALL && ((L->kernel == TSU_KERNEL_SMALL) || (L->kernel == TSU_KERNEL_AUTO && small_supported(L)));
+    int use_tiled = !use_small && ((L->kernel == TSU_KERNEL_TILED) || (L->kernel == TSU_KERNEL_AUTO && tsu_ising2d_tiled_supported(L)));
     if (part != TSU_PART_ALL && !(use_tiled && tsu_ising2d_tiled_part_supported(L)))
         return tsu_fail(ctx, TSU_E_UNSUPPORTED, "ising2d_sweep_part: split sweeps need a slab on the tiled kernel with rows %% 64 == 0");
-    if (use_tiled) {
+    if (use_small) {
+        K1Params p = make_params(L, L->alloc[L->cur]);
+        K1Table tbl;
+        memcpy(tbl.t, L->table, sizeof(tbl.t));
+        p.k0 = (uint32_t)seed;
+        p.k1 = (uint32_t)(seed >> 32);
+        p.tag_hi = TSU_TAG_ISING_HI | (replica << 8);
+        p.tag_lo = TSU_TAG_ISING_LO | (replica << 8);
+        const int nchunks = (L->cols + 15) >> 4, tasks = L->rows * nchunks;
+        const unsigned threads = tasks >= 1024 ? 1024u : (unsigned)((tasks + 63) / 64 * 64);
+        const size_t lds_bytes = (size_t)tasks * 16;
+        static bool attr_set = false;
+        if (!attr_set) {
+            TSU_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k1_small, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            attr_set = true;
+        }
+        k1_small<<<1, threads, lds_bytes, ctx->stream>>>(p, tbl, sweep0, n_sweeps);
+        TSU_HIP_TRY(ctx, hipGetLastError());
+    } else if (use_tiled) {
         int rc = tsu_ising2d_tiled_sweep(L, n_sweeps, seed, sweep0, replica, part);
         if (rc != TSU_OK) return rc;
     } else {

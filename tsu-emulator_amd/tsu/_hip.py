@@ -15,7 +15,7 @@ TSU_OK = 0
 TSU_E_INVALID, TSU_E_NOMEM, TSU_E_HIP, TSU_E_RCCL, TSU_E_UNSUPPORTED = -1, -2, -3, -4, -5
 MODE_PHYSICAL, MODE_COMPAT = 0, 1
 DTYPE_F64, DTYPE_F32 = 0, 1
-KERNEL_AUTO, KERNEL_GENERIC, KERNEL_TILED = 0, 1, 2
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_TILED, KERNEL_SMALL = 0, 1, 2, 3
 PART_ALL, PART_INTERIOR, PART_BOUNDARY = 0, 1, 2
 
 
