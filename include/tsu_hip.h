@@ -124,6 +124,14 @@ int tsu_ising2d_sweep_part(tsu_ising2d* lat, int n_sweeps, uint64_t seed, uint32
  * the row below the slab is included when that row exists).  M = sum_s/N, E = -J*sum_bonds - h*sum_s. */
 int tsu_ising2d_observables(tsu_ising2d* lat, int64_t* sum_s, int64_t* sum_bonds);
 
+/* Many independent lattices at once (one per temperature of a scan, ising.py:424-476; replicas of a tempering
+ * ladder): lattice i does n_sweeps sweeps with its own thresholds, seeds[i], sweep0s[i], replicas[i] -- the same
+ * results as n calls of tsu_ising2d_sweep.  Lattices that fit the one-workgroup kernel (TSU_KERNEL_SMALL) run as ONE
+ * launch, one workgroup each; others are swept one after the other.  observables_batch: one synchronisation for all. */
+int tsu_ising2d_sweep_batch(tsu_ising2d* const* lats, int n_lats, int n_sweeps, const uint64_t* seeds,
+                            const uint32_t* sweep0s, const uint32_t* replicas);
+int tsu_ising2d_observables_batch(tsu_ising2d* const* lats, int n_lats, int64_t* sum_s, int64_t* sum_bonds);
+
 /* device address of local row r in [-ghost, rows+ghost) and the row pitch in bytes, for halo exchange
  * by the host (RCCL send/recv through torch.distributed on the same stream) */
 int tsu_ising2d_row_ptr(tsu_ising2d* lat, int local_row, void** device_ptr, size_t* pitch_bytes);

@@ -176,6 +176,28 @@ def test_ising2d_replica_and_fill(hip):
     np.testing.assert_array_equal(lat.get_spins(), want)
 
 
+@pytest.mark.parametrize("rows,cols,periodic", [(32, 32, True), (20, 20, False), (64, 256, True), (128, 1024, True)])
+def test_ising2d_sweep_batch_equals_one_by_one(hip, rows, cols, periodic):
+    """tsu_ising2d_sweep_batch / observables_batch: lattices at different temperatures, seeds, counters and replica
+    ids advance together (one launch when they fit the one-workgroup kernel) == each swept alone == the oracle."""
+    Ts = [1.5, 2.0, 2.269185, 3.0, 4.5]
+    lats, want = [], []
+    for i, T in enumerate(Ts):
+        lat = hip.Lattice(rows, cols, periodic)
+        lat.randomize(100 + i, replica=i)
+        lat.set_model(1.0, 0.05 * i, T)
+        lats.append(lat)
+        table = ora.ising2d_thresholds(1.0, 0.05 * i, T, 0)
+        s0 = ora.ising2d_randomize(rows, cols, 100 + i, replica=i)
+        want.append(ora.ising2d_sweep(s0, periodic, table, 9, 100 + i, sweep0=3 * i, replica=i))
+    hip.sweep_batch(lats, 9, [100 + i for i in range(len(Ts))], [3 * i for i in range(len(Ts))], list(range(len(Ts))))
+    obs = hip.observables_batch(lats)
+    for i, lat in enumerate(lats):
+        np.testing.assert_array_equal(lat.get_spins(), want[i])
+        assert obs[i] == ora.ising2d_observables(want[i], periodic) == lat.observables()
+        lat.close()
+
+
 def test_ising2d_argument_errors(hip):
     with pytest.raises(hip.UnsupportedError):
         hip.Lattice(5, 8, True)  # odd periodic dimension has no 2-colouring

@@ -14,6 +14,8 @@
 //   hi16 = (half (m & 1) of W[m >> 1]) ^ 0x8000; lo16 = the same half of the TAG_LO block; u = hi16 << 16 | lo16;
 //   spin <- +1 iff u < table[deg * 5 + up].  lo16 is only evaluated when hi16 ties with the threshold's
 //   top 16 bits (probability 2^-16 per site), which cannot change the outcome of the 32-bit comparison.
+#include <vector>
+
 #include "ising2d.h"
 
 struct K1Params {
@@ -179,6 +181,50 @@ __global__ __launch_bounds__(1024) void k1_small(K1Params p, K1Table tbl, uint32
     const int nchunks = (p.cols + 15) >> 4;
     const int lp = 16 * nchunks;  // LDS row pitch: whole chunks, pad bytes 0 like the HBM rows
     if (tid < 25) s_tbl[tid] = tbl.t[tid];
+    for (int t = tid; t < p.rows * nchunks; t += nt) {
+        const int r = t / nchunks, q = t - r * nchunks;
+        *reinterpret_cast<uint4*>(s_lat + r * lp + 16 * q) = *reinterpret_cast<const uint4*>(p.base + (long long)r * p.pitch + 16 * q);
+    }
+    __syncthreads();
+    for (int hsi = 0; hsi < 2 * n_sweeps; ++hsi) {
+        const int colour = hsi & 1;
+        const uint32_t hs = 2u * (sweep0 + (uint32_t)(hsi >> 1)) + (uint32_t)colour;
+        for (int t = tid; t < p.rows * nchunks; t += nt) {
+            const int r = t / nchunks, q = t - r * nchunks;
+            const int par = (r + colour) & 1;
+            int8_t* row = s_lat + r * lp;
+            const int8_t* up_row = r > 0 ? row - lp : (p.periodic ? s_lat + (p.rows - 1) * lp : nullptr);
+            const int8_t* dn_row = r < p.rows - 1 ? row + lp : (p.periodic ? s_lat : nullptr);
+            k1_update_octet(p, s_tbl, row, up_row, dn_row, row + 16 * q, q, (long long)r, par, nchunks, hs);
+        }
+        __syncthreads();
+    }
+    for (int t = tid; t < p.rows * nchunks; t += nt) {
+        const int r = t / nchunks, q = t - r * nchunks;
+        *reinterpret_cast<uint4*>(p.out + (long long)r * p.pitch + 16 * q) = *reinterpret_cast<const uint4*>(s_lat + r * lp + 16 * q);
+    }
+}
+
+// k1_small for many lattices of one shape: workgroup b sweeps lattice b (own buffer, thresholds, seed, counters)
+struct K1BatchItem {
+    K1Params p;
+    K1Table tbl;
+    uint32_t sweep0;
+};
+
+__global__ __launch_bounds__(1024) void k1_small_batch(const K1BatchItem* __restrict__ items, int n_sweeps) {
+    extern __shared__ int8_t s_lat[];
+    __shared__ uint64_t s_tbl[25];
+    __shared__ K1Params sp;
+    const K1BatchItem& it = items[blockIdx.x];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (tid == 0) sp = it.p;
+    if (tid < 25) s_tbl[tid] = it.tbl.t[tid];
+    __syncthreads();
+    const K1Params& p = sp;
+    const uint32_t sweep0 = it.sweep0;
+    const int nchunks = (p.cols + 15) >> 4;
+    const int lp = 16 * nchunks;
     for (int t = tid; t < p.rows * nchunks; t += nt) {
         const int r = t / nchunks, q = t - r * nchunks;
         *reinterpret_cast<uint4*>(s_lat + r * lp + 16 * q) = *reinterpret_cast<const uint4*>(p.base + (long long)r * p.pitch + 16 * q);
@@ -633,6 +679,81 @@ int tsu_ising2d_observables(tsu_ising2d* L, int64_t* sum_s, int64_t* sum_bonds) 
     *sum_s = h[0];
     *sum_bonds = h[1];
     return check_persist_error(L);
+}
+
+int tsu_ising2d_sweep_batch(tsu_ising2d* const* lats, int n_lats, int n_sweeps, const uint64_t* seeds, const uint32_t* sweep0s,
+                            const uint32_t* replicas) {
+    if (!lats || n_lats < 1 || !lats[0]) return TSU_E_INVALID;
+    tsu_ctx* ctx = lats[0]->ctx;
+    TSU_REQUIRE(ctx, seeds && sweep0s && replicas, "ising2d_sweep_batch: seeds, sweep0s and replicas are per-lattice arrays");
+    TSU_REQUIRE(ctx, n_sweeps >= 0, "ising2d_sweep: n_sweeps must be >= 0");
+    bool one_launch = true;
+    for (int i = 0; i < n_lats; ++i) {
+        tsu_ising2d* L = lats[i];
+        TSU_REQUIRE(ctx, L && L->ctx == ctx, "ising2d_sweep_batch: lattice %d is NULL or belongs to another context", i);
+        TSU_REQUIRE(ctx, L->have_table, "ising2d_sweep: call tsu_ising2d_set_model / set_thresholds first");
+        TSU_REQUIRE(ctx, (uint64_t)sweep0s[i] + (uint64_t)n_sweeps <= (1ull << 31), "ising2d_sweep: sweep counter overflow");
+        one_launch = one_launch && small_supported(L) && L->rows == lats[0]->rows && L->cols == lats[0]->cols &&
+                     (L->kernel == TSU_KERNEL_AUTO || L->kernel == TSU_KERNEL_SMALL);
+    }
+    if (n_sweeps == 0) return TSU_OK;
+    if (!one_launch) {
+        for (int i = 0; i < n_lats; ++i) {
+            const int rc = tsu_ising2d_sweep(lats[i], n_sweeps, seeds[i], sweep0s[i], replicas[i]);
+            if (rc != TSU_OK) return rc;
+        }
+        return TSU_OK;
+    }
+    std::vector<K1BatchItem> items((size_t)n_lats);
+    for (int i = 0; i < n_lats; ++i) {
+        tsu_ising2d* L = lats[i];
+        K1BatchItem& it = items[(size_t)i];
+        it.p = make_params(L, L->alloc[L->cur]);
+        memcpy(it.tbl.t, L->table, sizeof(it.tbl.t));
+        it.p.k0 = (uint32_t)seeds[i];
+        it.p.k1 = (uint32_t)(seeds[i] >> 32);
+        it.p.tag_hi = TSU_TAG_ISING_HI | (replicas[i] << 8);
+        it.p.tag_lo = TSU_TAG_ISING_LO | (replicas[i] << 8);
+        it.sweep0 = sweep0s[i];
+    }
+    const size_t bytes = items.size() * sizeof(K1BatchItem);
+    K1BatchItem* d_items = nullptr;
+    TSU_HIP_TRY(ctx, hipMalloc(&d_items, bytes));
+    hipError_t e = hipMemcpyAsync(d_items, items.data(), bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        const int nchunks = (lats[0]->cols + 15) >> 4, tasks = lats[0]->rows * nchunks;
+        const unsigned threads = tasks >= 1024 ? 1024u : (unsigned)((tasks + 63) / 64 * 64);
+        k1_small_batch<<<(unsigned)n_lats, threads, (size_t)tasks * 16, ctx->stream>>>(d_items, n_sweeps);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // `items` and d_items live until the launch has read them
+    (void)hipFree(d_items);
+    if (e != hipSuccess) return tsu_fail(ctx, TSU_E_HIP, "ising2d_sweep_batch: %s", hipGetErrorString(e));
+    return TSU_OK;
+}
+
+int tsu_ising2d_observables_batch(tsu_ising2d* const* lats, int n_lats, int64_t* sum_s, int64_t* sum_bonds) {
+    if (!lats || n_lats < 1 || !lats[0]) return TSU_E_INVALID;
+    tsu_ctx* ctx = lats[0]->ctx;
+    TSU_REQUIRE(ctx, sum_s && sum_bonds, "ising2d_observables: NULL output");
+    std::vector<int64_t> h((size_t)2 * n_lats);
+    for (int i = 0; i < n_lats; ++i) {
+        tsu_ising2d* L = lats[i];
+        TSU_REQUIRE(ctx, L && L->ctx == ctx, "ising2d_observables_batch: lattice %d is NULL or belongs to another context", i);
+        K1Params p = make_params(L, L->alloc[L->cur]);
+        TSU_HIP_TRY(ctx, hipMemsetAsync(L->d_obs, 0, 2 * sizeof(int64_t), ctx->stream));
+        long long work = (long long)L->rows * ((L->cols + 15) / 16);
+        unsigned blocks = (unsigned)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096);
+        k4_observables<<<blocks, 256, 0, ctx->stream>>>(p, (long long*)L->d_obs);
+        TSU_HIP_TRY(ctx, hipMemcpyAsync(&h[(size_t)2 * i], L->d_obs, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    TSU_HIP_TRY(ctx, hipGetLastError());
+    TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n_lats; ++i) {
+        sum_s[i] = h[(size_t)2 * i];
+        sum_bonds[i] = h[(size_t)2 * i + 1];
+    }
+    return TSU_OK;
 }
 
 int tsu_ising2d_row_ptr(tsu_ising2d* L, int local_row, void** device_ptr, size_t* pitch_bytes) {

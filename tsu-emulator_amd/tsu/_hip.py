@@ -63,6 +63,9 @@ SIGNATURES = {
     "tsu_ising2d_sweep": (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32]),
     "tsu_ising2d_sweep_part": (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]),
     "tsu_ising2d_observables": (C.c_int, [_vp, _i64p, _i64p]),
+    "tsu_ising2d_sweep_batch": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
+                                          C.POINTER(C.c_uint32)]),
+    "tsu_ising2d_observables_batch": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "tsu_ising2d_row_ptr": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "tsu_ising2d_set_timing": (C.c_int, [_vp, C.c_int]),
     "tsu_ising2d_last_sweep_ms": (C.c_int, [_vp, _f32p]),
@@ -264,6 +267,31 @@ class Lattice:
         ms = C.c_float(0)
         self.ctx.check(self.lib.tsu_ising2d_last_sweep_ms(self.h, C.byref(ms)))
         return ms.value
+
+
+def sweep_batch(lattices, n_sweeps, seeds, sweep0s, replicas=None):
+    """n_sweeps sweeps of every lattice (own thresholds, seed, sweep counter, replica id); lattices that fit the
+    one-workgroup kernel run concurrently in one launch.  Same results as sweeping them one by one."""
+    n = len(lattices)
+    if n == 0:
+        return
+    ctx = lattices[0].ctx
+    hs = (_vp * n)(*[l.h for l in lattices])
+    sd = (C.c_uint64 * n)(*[int(v) for v in seeds])
+    s0 = (C.c_uint32 * n)(*[int(v) for v in sweep0s])
+    rp = (C.c_uint32 * n)(*([0] * n if replicas is None else [int(v) for v in replicas]))
+    ctx.check(lattices[0].lib.tsu_ising2d_sweep_batch(hs, n, int(n_sweeps), sd, s0, rp))
+
+
+def observables_batch(lattices):
+    """[(sum of spins, sum over bonds)] of every lattice with one synchronisation."""
+    n = len(lattices)
+    if n == 0:
+        return []
+    hs = (_vp * n)(*[l.h for l in lattices])
+    a, b = (C.c_int64 * n)(), (C.c_int64 * n)()
+    lattices[0].ctx.check(lattices[0].lib.tsu_ising2d_observables_batch(hs, n, a, b))
+    return [(int(a[i]), int(b[i])) for i in range(n)]
 
 
 class DenseSystem:

@@ -434,19 +434,32 @@ def temperature_scan(size, temperatures, coupling: float = 1.0, n_equilibrate: i
     temperatures = np.asarray(temperatures, dtype=float)
     out = {k: np.zeros(len(temperatures)) for k in ("magnetization", "energy", "susceptibility", "specific_heat")}
     out["temperatures"] = temperatures
+    # all temperatures advance together: lattices small enough for the one-workgroup kernel share ONE launch per
+    # batch of sweeps (one workgroup per temperature) and one synchronisation per measurement; the streams (seed + i,
+    # own sweep counter) and hence the results are those of sweeping the models one after the other
+    models = [IsingModel2D(size, coupling=coupling, temperature=float(T), periodic=periodic, seed=seed + i,
+                           bias_mode=bias_mode, initial=initial) for i, T in enumerate(temperatures)]
+
+    def advance(n_sweeps):
+        for m in models:
+            m._lat.set_model(m.coupling, m.external_field, m.temperature, m._mode)
+        _hip.sweep_batch([m._lat for m in models], n_sweeps, [m.seed for m in models], [m.sweep_count for m in models])
+        for m in models:
+            m.sweep_count += int(n_sweeps)
+
+    if models:
+        advance(int(n_equilibrate))
+    Ms, Es = np.zeros((len(models), n_measure)), np.zeros((len(models), n_measure))
+    for j in range(n_measure if models else 0):
+        advance(int(measure_every))
+        for i, (sum_s, sum_bonds) in enumerate(_hip.observables_batch([m._lat for m in models])):
+            Ms[i, j] = sum_s / models[i].n_spins
+            Es[i, j] = -models[i].coupling * float(sum_bonds) - models[i].external_field * float(sum_s)
     for i, T in enumerate(temperatures):
-        m = IsingModel2D(size, coupling=coupling, temperature=float(T), periodic=periodic, seed=seed + i,
-                         bias_mode=bias_mode, initial=initial)
-        m.equilibrate(n_sweeps=n_equilibrate)
-        Ms, Es = np.zeros(n_measure), np.zeros(n_measure)
-        for j in range(n_measure):
-            m.gibbs_update(measure_every)
-            Ms[j] = m.magnetization()
-            Es[j] = m.energy()
-        N = m.n_spins
-        out["magnetization"][i] = np.mean(np.abs(Ms))
-        out["energy"][i] = np.mean(Es) / N
-        out["susceptibility"][i] = (np.mean(Ms ** 2) - np.mean(np.abs(Ms)) ** 2) * N / T
-        out["specific_heat"][i] = (np.mean(Es ** 2) - np.mean(Es) ** 2) / (T ** 2 * N)
-        del m
+        N = models[i].n_spins
+        out["magnetization"][i] = np.mean(np.abs(Ms[i]))
+        out["energy"][i] = np.mean(Es[i]) / N
+        out["susceptibility"][i] = (np.mean(Ms[i] ** 2) - np.mean(np.abs(Ms[i])) ** 2) * N / T
+        out["specific_heat"][i] = (np.mean(Es[i] ** 2) - np.mean(Es[i]) ** 2) / (T ** 2 * N)
+    del models
     return out
