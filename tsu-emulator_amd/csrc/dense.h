@@ -13,7 +13,6 @@ struct tsu_dense {
     int8_t* state;   // current state ({0,1})
     int8_t* state2;  // next state: a sweep reads `state` (frozen) and writes `state2`, then the two are swapped
     double* field;
-    int* flips;      // per block: [0] = count, [1..DB] = site, delta pairs packed (site << 1 | (delta > 0))
     int64_t* order;  // device copy of the visiting order (n_sweeps * n) or NULL
     double* uniforms;
     size_t order_cap, uni_cap;

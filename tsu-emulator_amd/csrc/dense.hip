@@ -5,15 +5,17 @@
 // (gibbs.py:73-77), s_i <- (u < p) (gibbs.py:126).  The visiting order is the reference's (range(n) or
 // the caller's permutation); what is parallel is the arithmetic, not the Markov chain.
 //
-// Per sweep:
-//   1. field f = J s + b for all sites: one streaming pass over J (the HBM-bound part, N^2 * sizeof(J)).
-//   2. the visiting order is cut into blocks of 64 positions.  For each block one wave
-//        - gathers the 64 x 64 sub-block of J into LDS,
-//        - resolves the 64 sites in order: a lane's pending decision only changes when an earlier site of
-//          the block actually flips, so the wave jumps from flip to flip (ballot + ffs) instead of walking
-//          all 64 sites; each flip applies its column of the sub-block to the 64 fields;
-//      then a grid-wide kernel applies the block's flips to the fields of every site outside the block
-//      (f_j += sum_i delta_i J[j, i], read as rows of J^T so that the access is coalesced).
+// Three paths, the same results (dispatch in tsu_dense_sweep):
+//   * natural order, n >= 128: dense_coop.hip -- the whole call in one cooperative launch (superblock fixed point);
+//   * the same fixed point with one launch per iteration (k2_sb_iter / k2_sb_finish) when a cooperative launch is
+//     not available;
+//   * k2_block: per sweep the field f = J s + b (k2_matvec), then the visiting order in blocks of 64 positions, one
+//     launch per block in which every workgroup gathers the 64 x 64 sub-block into LDS, a wave resolves the 64
+//     sites in order by jumping from flip to flip (ballot + ffs: a lane's pending decision only changes when an
+//     earlier site of the block actually flips), and the block's flips are added to the other fields through rows
+//     of J^T.  Serves custom visiting orders (np.random.permutation), tiny systems and the never-seen case of a
+//     superblock that did not converge.
+//   * k2_small (n <= 64, natural order): a whole sample_boltzmann run in one launch of a single wave.
 //
 // Uniforms: replayed doubles from the host (bit-exact replay of np.random.rand) or Philox doubles keyed by
 // (site, sweep): a = W[2(i&1)] >> 5, b = W[2(i&1)+1] >> 6, u = (a 2^26 + b) / 2^53 with
@@ -34,81 +36,6 @@ __global__ __launch_bounds__(256) void k2_matvec(const TJ* __restrict__ J, const
     for (int j = lane; j < n; j += 64) acc += (double)row[j] * (double)s[j];
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if (lane == 0) f[wave] = acc + (bias ? bias[wave] : 0.0);
-}
-
-// one wave resolves positions [pos0, pos0 + cnt) of the visiting order
-template <typename TJ>
-__global__ __launch_bounds__(64) void k2_resolve(const TJ* __restrict__ J, int8_t* __restrict__ s, double* __restrict__ f,
-                                                const int64_t* __restrict__ order, const double* __restrict__ uniforms,
-                                                int* __restrict__ flips, int n, int pos0, int cnt, double T, uint32_t sweep,
-                                                uint32_t tag, uint32_t k0, uint32_t k1) {
-    __shared__ double sub[DB][DB + 1];  // sub[i][k] = J[site_k][site_i]
-    __shared__ int sites[DB];
-    int lane = threadIdx.x;
-    int site = -1;
-    if (lane < cnt) site = order ? (int)order[pos0 + lane] : pos0 + lane;
-    sites[lane] = site;
-    __syncthreads();
-    for (int i = 0; i < cnt; ++i) {
-        int si = sites[i];
-        if (lane < cnt) sub[i][lane] = (double)J[(size_t)site * n + si];
-    }
-    __syncthreads();
-    double fk = 0.0, u = 2.0;
-    int bit = 0;
-    if (lane < cnt) {
-        fk = f[site];
-        bit = s[site];
-        u = uniforms ? uniforms[pos0 + lane] : dense_uniform((uint32_t)site, sweep, tag, k0, k1);
-    }
-    int nflip = 0;
-    int cursor = 0;
-    while (true) {
-        int cand = (lane < cnt && u < sigmoid_clamped(fk / T)) ? 1 : 0;
-        unsigned long long want = __ballot((lane >= cursor) && (lane < cnt) && (cand != bit));
-        if (want == 0ull) break;
-        int i = __ffsll((long long)want) - 1;  // first position at or after the cursor whose decision is a flip
-        int delta = __shfl(cand - bit, i, 64);
-        if (lane == i) bit = cand;
-        if (lane < cnt) fk += (double)delta * sub[i][lane];
-        if (lane == 0) flips[1 + nflip] = (sites[i] << 1) | (delta > 0 ? 1 : 0);
-        ++nflip;
-        cursor = i + 1;
-    }
-    if (lane < cnt) {
-        s[site] = (int8_t)bit;
-        f[site] = fk;
-    }
-    if (lane == 0) flips[0] = nflip;
-}
-
-// f_j += sum over the block's flips delta_i * J[j, i] for every site j NOT in the block (the block's own
-// fields were updated during the resolve).  Reads rows of J^T: JT[i, j] = J[j, i].
-template <typename TJ>
-__global__ __launch_bounds__(256) void k2_propagate(const TJ* __restrict__ JT, double* __restrict__ f,
-                                                   const int* __restrict__ flips, const int64_t* __restrict__ order,
-                                                   int n, int pos0, int cnt) {
-    __shared__ int sh_sites[DB];
-    __shared__ int sh_flips[DB + 1];
-    int nflip = flips[0];
-    if (nflip == 0) return;
-    if (threadIdx.x < cnt) sh_sites[threadIdx.x] = order ? (int)order[pos0 + threadIdx.x] : pos0 + threadIdx.x;
-    if (threadIdx.x < nflip) sh_flips[threadIdx.x] = flips[1 + threadIdx.x];
-    __syncthreads();
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    bool inside = false;
-    if (!order) inside = (j >= pos0 && j < pos0 + cnt);
-    else
-        for (int k = 0; k < cnt; ++k) inside |= (sh_sites[k] == j);
-    if (inside) return;
-    double acc = 0.0;
-    for (int k = 0; k < nflip; ++k) {
-        int v = sh_flips[k];
-        double d = (v & 1) ? 1.0 : -1.0;
-        acc += d * (double)JT[(size_t)(v >> 1) * n + j];
-    }
-    f[j] += acc;
 }
 
 // One block of 64 visiting-order positions per launch, ALL workgroups: every workgroup gathers the 64 x 64
@@ -534,7 +461,6 @@ int tsu_dense_create(tsu_ctx* ctx, int n, const void* J_host, int dtype, const d
     if (e == hipSuccess) e = hipMemsetAsync(d->state, 0, (size_t)n, ctx->stream);
     if (e == hipSuccess) e = hipMalloc(&d->state2, (size_t)n);
     if (e == hipSuccess) e = hipMalloc(&d->field, (size_t)n * 8);
-    if (e == hipSuccess) e = hipMalloc(&d->flips, (DB + 1) * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&d->d_energy, 8);
     if (e == hipSuccess) e = hipMalloc(&d->backup, (size_t)n);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -557,7 +483,6 @@ int tsu_dense_destroy(tsu_dense* d) {
     if (d->state) (void)hipFree(d->state);
     if (d->state2) (void)hipFree(d->state2);
     if (d->field) (void)hipFree(d->field);
-    if (d->flips) (void)hipFree(d->flips);
     if (d->order) (void)hipFree(d->order);
     if (d->uniforms) (void)hipFree(d->uniforms);
     if (d->d_energy) (void)hipFree(d->d_energy);
