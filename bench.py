@@ -161,6 +161,9 @@ def main():
     ap.add_argument("--sweeps-per-exchange", type=int, default=0, help="N>1: 0 = auto, the multiple of sweeps-per-launch nearest 64")
     ap.add_argument("--ramp-steps", type=int, default=20, help="untimed steps before the W warmup steps (GPU clock ramp, ~30 ms)")
     ap.add_argument("--sweeps-per-launch", type=int, default=0, help="0 = auto: 8 up to 4096^2 per GPU, 5 above")
+    ap.add_argument("--strong", action="store_true",
+                    help="N>1: ONE L x L lattice cut into N slabs of L/N rows (BASELINE configs[3]: --L 16384 --gpus 8) "
+                         "instead of the default weak scaling (L x L per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
@@ -188,8 +191,13 @@ def main():
     ctx = hip.Context(local_rank)
     hip.Context._default = ctx
     L = args.L
-    k = args.sweeps_per_launch or (8 if L * L <= 4096 * 4096 else 5)
-    spx = args.sweeps_per_exchange or k * round(64 / k)   # sweeps between two halo exchanges (2*spx ghost rows)
+    rows_local = L // world if (args.strong and world > 1) else L  # rows of this rank's slab
+    if args.strong and world > 1 and L % world:
+        raise SystemExit("--strong needs L divisible by the number of GPUs")
+    k = args.sweeps_per_launch or (8 if rows_local * L <= 4096 * 4096 else 5)
+    if args.strong and world > 1 and not args.sweeps_per_launch:
+        k = 8  # thin slabs run 256-row tiles, one per CU (tools/shape_scan.py)
+    spx = args.sweeps_per_exchange or (32 if (args.strong and world > 1) else k * round(64 / k))  # sweeps per halo exchange
     sps = args.sweeps_per_step or 4 * spx                  # one step: ~1.6 ms at 4096^2
     if world > 1 and sps % spx:
         raise SystemExit("--sweeps-per-step must be a multiple of --sweeps-per-exchange")
@@ -211,7 +219,7 @@ def main():
         parallelism = "single GPU"
     else:
         # one halo exchange per spx sweeps; the slab keeps its own halo exact in between (deep ghost rows)
-        slab = SlabLattice(L, L, periodic=True, sweeps_per_exchange=spx, seed=42)
+        slab = SlabLattice(rows_local, L, periodic=True, sweeps_per_exchange=spx, seed=42)
         slab.lat.set_kernel(hip.KERNEL_AUTO, k)
         slab.randomize()
         slab.set_model(1.0, 0.0, T_C, hip.MODE_PHYSICAL)
@@ -223,7 +231,7 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
-        parallelism = (f"{world} row slabs of {L}x{L}, RCCL send/recv halo ({2 * spx} rows every {spx} sweeps = "
+        parallelism = (f"{world} row slabs of {rows_local}x{L}, RCCL send/recv halo ({2 * spx} rows every {spx} sweeps = "
                        f"{spx // k} launches), no collective")
 
     # The first ~10 ms of work after idle run ~6 % slower (clock ramp): spend them before the warmup steps.
@@ -245,13 +253,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, ev_ms = float(t[0]), float(t[1])
 
-    updates = float(L) * L * world * sps * args.steps
+    updates = float(rows_local) * L * world * sps * args.steps
     value = updates / elapsed
     n_launches = args.steps * ((sps + k - 1) // k)
     avg_launch_ms = ev_ms / n_launches
     # algorithmic bytes: 2 B per spin update (int8 read + write); a launch of k sweeps on this GPU's L x L sites
     # carries 2 L^2 k bytes (the last launch of a step may be shorter, so average over the step)
-    alg_bytes_per_launch = 2.0 * L * L * sps / ((sps + k - 1) // k)
+    alg_bytes_per_launch = 2.0 * rows_local * L * sps / ((sps + k - 1) // k)
     achieved = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -270,11 +278,11 @@ def main():
         out = {
             "metric": "spin-updates/sec on L×L 2D Ising Gibbs sweep; achieved HBM GB/s vs peak",
             "value": value, "unit": "spin-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong" if (args.strong and world > 1) else "weak", "vs_baseline": None,
             "dtype": "int8", "data": "synthetic (Philox i.i.d. +-1 start, seed 42)",
             "backend": backend if world > 1 else None,
-            "config": {"workload": f"IsingModel2D {L}x{L} per GPU at T_c=2.269185, J=1, h=0, periodic, checkerboard Gibbs sweep "
-                                   "(BASELINE.json configs[1])", "L": L, "lattice_rows": L * world, "lattice_cols": L,
+            "config": {"workload": f"IsingModel2D {rows_local}x{L} per GPU at T_c=2.269185, J=1, h=0, periodic, checkerboard Gibbs sweep "
+                                   "(BASELINE.json configs[1])", "L": L, "lattice_rows": rows_local * world, "lattice_cols": L,
                        "sweeps_per_step": sps, "sweeps_per_launch": k, "sweeps_per_exchange": spx if world > 1 else None,
                        "clock_ramp_steps_before_warmup": args.ramp_steps, "kernel": "k1_tiled2 (LDS halo tiles, row-pair inner loop)",
                        "bias_mode": "physical", "parallelism": parallelism, "launches": n_launches,
@@ -284,7 +292,7 @@ def main():
                          "note": "achieved = algorithmic 2 B/spin-update x L^2 x k per launch / avg launch time (HIP events "
                                  "on the launch stream over the timed region); the kernel keeps the tile in LDS for k "
                                  "sweeps, so real HBM traffic is ~2/k B per update and the kernel is VALU (Philox) bound"},
-            "observables": {"M": s / (float(L) * L * world), "E_per_site": -b / (float(L) * L * world),
+            "observables": {"M": s / (float(rows_local) * L * world), "E_per_site": -b / (float(rows_local) * L * world),
                             "note": "physical mode, random start; u(T_c) = -sqrt(2) = -1.4142 is approached slowly (critical slowing down)"},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -511,7 +511,7 @@ const TileVariant kVariants[] = {
     {128, 32, 512, k1_tiled2<128, 32, 512, 6>, k1_persist<128, 32, 512, 6>}, // 19
     {128, 32, 768, k1_tiled2<128, 32, 768, 6>}, // 20: 12 waves per workgroup, 2 workgroups per CU = 6 waves/SIMD
     {128, 32, 640, k1_tiled2<128, 32, 640, 5>}, // 21
-    {256, 32, 1024, k1_tiled2<256, 32, 1024, 4>}, // 22: one 148 KB workgroup per CU
+    {256, 32, 1024, k1_tiled2<256, 32, 1024, 4>, nullptr, k1_tiled2<256, 32, 1024, 4, true>}, // 22: one 148 KB workgroup per CU
     {112, 32, 512, k1_tiled2<112, 32, 512>},      // 23
     {96, 32, 512, k1_tiled2<96, 32, 512, 6>},     // 24
     {160, 32, 512, k1_tiled2<160, 32, 512>},      // 25
@@ -529,10 +529,16 @@ int pick_variant(const tsu_ising2d* L) {
     if (env >= 0 && env < kNumVariants) {
         v = env;
     } else {
-        // measured on MI355X (profiles/): 128-row tiles carry the least halo work; small lattices need all 16
-        // waves of a CU in one workgroup because they only have one tile per CU
-        const long long sites = (long long)L->rows * L->cols;
-        v = sites <= 4096ll * 4096ll ? 9 : 8;
+        // measured on MI355X (profiles/r01_k1_experiments.txt): 128-row tiles with two 512-thread workgroups per CU
+        // when the lattice gives every CU several tiles; a lattice with at most one such tile per CU needs all 16
+        // waves of the CU in one workgroup; one with ABOUT TWO per CU (2048 x 16384, 4096 x 8192: everything starts
+        // and ends together, nothing hides the stage/store phases) does better with 256-row tiles, one per CU
+        const int cus = L->ctx->cus > 0 ? L->ctx->cus : 256;
+        const long long tx = (L->cols / 16 + 31) / 32;
+        const long long n128 = ((L->rows + 127) / 128) * tx, n256 = ((L->rows + 255) / 256) * tx;
+        if (n128 <= cus) v = 9;
+        else if (n128 <= 2 * cus && n256 <= cus && 10 * n256 >= 7 * cus) v = 22;
+        else v = 8;
         if (L->rows < 256) v = 6;
     }
     // a variant must fit the lattice (tile not wider than the lattice; single wrap of the global row index)
@@ -567,7 +573,10 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
         TSU_HIP_TRY(ctx, hipMemsetAsync(L->alloc[1], 0, bytes, ctx->stream));
     }
     // sweeps per launch: more sweeps amortise the tile load/store and the launch gap, fewer carry less halo work
-    int kmax = L->sweeps_per_launch > 0 ? L->sweeps_per_launch : ((long long)L->rows * L->cols <= 4096ll * 4096ll ? 8 : 5);
+    // (one workgroup per CU, or a small lattice: 8; large lattices with two workgroups per CU that overlap each other's
+    // stage/store phases: 5)
+    int kmax = L->sweeps_per_launch > 0 ? L->sweeps_per_launch
+                                        : ((tv.threads >= 1024 || (long long)L->rows * L->cols <= 4096ll * 4096ll) ? 8 : 5);
     if (kmax > KMAX) kmax = KMAX;
     const bool open_whole = !L->periodic && L->ghost == 0 && L->total_rows == L->rows;
     const bool slab = !L->wrap_rows && !open_whole;
