@@ -164,6 +164,12 @@ int tsu_dense_sweep(tsu_dense* d, double T, int n_sweeps, const int64_t* order, 
 int tsu_dense_sample(tsu_dense* d, double T, int n_burnin, int n_sweeps, int n_samples, const int64_t* order,
                      uint64_t seed, uint32_t sweep0, uint32_t replica, const double* replay_uniforms,
                      int8_t* samples_host);
+/* The loop of GibbsSampler.simulated_annealing (tsu/gibbs.py:366-391) from the resident state: step s does ONE sweep
+ * at temperatures[s] and records the state; states_host receives n_steps*n bits (the caller evaluates the energies
+ * and keeps the best, with the reference's own expression).  order / replay_uniforms: one row per step.  n <= 64 in
+ * natural order: one launch of a single wave for the whole schedule. */
+int tsu_dense_anneal(tsu_dense* d, const double* temperatures, int n_steps, const int64_t* order, uint64_t seed,
+                     uint32_t sweep0, uint32_t replica, const double* replay_uniforms, int8_t* states_host);
 int tsu_dense_energy(tsu_dense* d, double* energy); /* -1/2 s^T J s - b^T s of the resident state */
 
 /* ------------------------------------------------------------------ Langevin (K3)

@@ -30,3 +30,17 @@ for rng in ("philox", "numpy"):
             x = s.sample_boltzmann(J, bias=h, n_samples=10000)
             rates.append(10000 / (time.time() - t0))
         print(f"rng={rng:6s} {name:24s} {np.median(rates):12.0f} samples/s   (reference publishes {PUBLISHED[name]}; x{np.median(rates) / PUBLISHED[name]:.1f})  mean bit {x.mean():.3f}", flush=True)
+
+# MAX-CUT by simulated annealing, n=15, 1000 steps (tsu/benchmarks/README.md:62, README.md:273: 17.6 +- 2.1 ms)
+rng0 = np.random.RandomState(7)
+W = np.triu((rng0.rand(15, 15) < 0.5).astype(float), 1)
+W = W + W.T
+for rng in ("philox", "numpy"):
+    ts = []
+    for trial in range(7):
+        np.random.seed(100 + trial)
+        s = GibbsSampler(GibbsConfig(temperature=1.0), rng=rng)
+        t0 = time.time()
+        best, e = s.simulated_annealing(-2.0 * W, bias=W.sum(1), n_steps=1000)  # E = -(cut weight)
+        ts.append(time.time() - t0)
+    print(f"rng={rng:6s} simulated_annealing n=15, 1000 steps: {np.median(ts[1:]) * 1e3:8.2f} ms   (reference publishes 17.6 ms)  cut found {-e:.0f} of {W.sum() / 2:.0f} edges", flush=True)

@@ -35,6 +35,8 @@ struct tsu_dense {
     size_t co_counts_cap;
     int8_t* samples;    // device buffer of recorded states (tsu_dense_sample)
     size_t samples_cap;
+    double* temps;      // device copy of an annealing schedule (tsu_dense_anneal)
+    size_t temps_cap;
     int co_disabled;    // cooperative launch unavailable or failed once: use the multi-launch path
 };
 

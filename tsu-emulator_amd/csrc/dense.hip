@@ -147,20 +147,24 @@ __global__ __launch_bounds__(256) void k2_block(const TJ* __restrict__ J, const 
 template <typename TJ>
 __global__ __launch_bounds__(64) void k2_small(const TJ* __restrict__ J, const double* __restrict__ bias, int8_t* __restrict__ state,
                                               const double* __restrict__ uniforms, int8_t* __restrict__ samples, int n, double T,
-                                              int n_burnin, int n_sweeps, int n_samples, uint32_t sweep0, uint32_t tag, uint32_t k0,
-                                              uint32_t k1) {
+                                              const double* __restrict__ temps, int n_burnin, int n_sweeps, int n_samples,
+                                              uint32_t sweep0, uint32_t tag, uint32_t k0, uint32_t k1) {
     __shared__ double col[DB][DB + 1];  // col[i][k] = J[k][i]
     const int lane = threadIdx.x;
     const bool on = lane < n;
     for (int i = 0; i < n; ++i) col[i][lane] = on ? (double)J[(size_t)lane * n + i] : 0.0;
     __syncthreads();
     const double bk = (on && bias) ? bias[lane] : 0.0;
-    const double invT = 1.0 / T;
+    double invT = 1.0 / T;  // or one temperature per sweep (an annealing schedule)
     int bit = on ? state[lane] : 0;
     const int total = n_burnin + n_samples * n_sweeps;
     int next_record = n_burnin + n_sweeps - 1, rec = 0;
     double u_next = (on && uniforms && total > 0) ? uniforms[lane] : 2.0;
     for (int sw = 0; sw < total; ++sw) {
+        if (temps) {
+            T = temps[sw];
+            invT = 1.0 / T;
+        }
         double u = 2.0;
         if (on) u = uniforms ? u_next : dense_uniform((uint32_t)lane, sweep0 + (uint32_t)sw, tag, k0, k1);
         if (on && uniforms && sw + 1 < total) u_next = uniforms[(size_t)(sw + 1) * n + lane];  // in flight during this sweep
@@ -492,6 +496,7 @@ int tsu_dense_destroy(tsu_dense* d) {
     if (d->sb_sync) (void)hipFree(d->sb_sync);
     if (d->backup) (void)hipFree(d->backup);
     if (d->samples) (void)hipFree(d->samples);
+    if (d->temps) (void)hipFree(d->temps);
     if (d->co_logit) (void)hipFree(d->co_logit);
     if (d->co_corr) (void)hipFree(d->co_corr);
     if (d->co_d0) (void)hipFree(d->co_d0);
@@ -601,9 +606,9 @@ int tsu_dense_sweep(tsu_dense* d, double T, int n_sweeps, const int64_t* order, 
     return dense_sweep_impl<float>(d, T, n_sweeps, order != nullptr, seed, sweep0, replica, replay_uniforms != nullptr);
 }
 
-int tsu_dense_sample(tsu_dense* d, double T, int n_burnin, int n_sweeps, int n_samples, const int64_t* order, uint64_t seed,
-                     uint32_t sweep0, uint32_t replica, const double* replay_uniforms, int8_t* samples_host) {
-    if (!d) return TSU_E_INVALID;
+// shared by tsu_dense_sample (one temperature) and tsu_dense_anneal (temps: one temperature per sweep, host array)
+static int dense_run(tsu_dense* d, double T, const double* temps, int n_burnin, int n_sweeps, int n_samples, const int64_t* order,
+                     uint64_t seed, uint32_t sweep0, uint32_t replica, const double* replay_uniforms, int8_t* samples_host) {
     tsu_ctx* ctx = d->ctx;
     TSU_REQUIRE(ctx, T > 0.0, "Temperature must be positive");
     TSU_REQUIRE(ctx, n_burnin >= 0 && n_sweeps > 0 && n_samples >= 0, "dense_sample: need n_burnin >= 0, n_sweeps > 0, n_samples >= 0");
@@ -614,12 +619,25 @@ int tsu_dense_sample(tsu_dense* d, double T, int n_burnin, int n_sweeps, int n_s
     const size_t out_bytes = (size_t)n_samples * n;
     if (d->samples_cap < out_bytes) {
         if (d->samples) (void)hipFree(d->samples);
+    if (d->temps) (void)hipFree(d->temps);
         d->samples = nullptr;
         d->samples_cap = 0;
         TSU_HIP_TRY(ctx, hipMalloc(&d->samples, out_bytes));
         d->samples_cap = out_bytes;
     }
     if (n <= DB && !order) {
+        const double* temps_dev = nullptr;
+        if (temps && total > 0) {
+            if (d->temps_cap < (size_t)total) {
+                if (d->temps) (void)hipFree(d->temps);
+                d->temps = nullptr;
+                d->temps_cap = 0;
+                TSU_HIP_TRY(ctx, hipMalloc(&d->temps, (size_t)total * 8));
+                d->temps_cap = (size_t)total;
+            }
+            TSU_HIP_TRY(ctx, hipMemcpyAsync(d->temps, temps, (size_t)total * 8, hipMemcpyHostToDevice, ctx->stream));
+            temps_dev = d->temps;
+        }
         const size_t cnt = (size_t)total * n;
         if (replay_uniforms && cnt) {
             if (d->uni_cap < cnt) {
@@ -635,22 +653,24 @@ int tsu_dense_sample(tsu_dense* d, double T, int n_burnin, int n_sweeps, int n_s
         if (total > 0) {
             if (d->dtype == TSU_DTYPE_F64)
                 k2_small<double><<<1, 64, 0, ctx->stream>>>((const double*)d->J, d->bias, d->state, replay_uniforms ? d->uniforms : nullptr,
-                                                            d->samples, n, T, n_burnin, n_sweeps, n_samples, sweep0, tag, (uint32_t)seed,
-                                                            (uint32_t)(seed >> 32));
+                                                            d->samples, n, T, temps_dev, n_burnin, n_sweeps, n_samples, sweep0, tag,
+                                                            (uint32_t)seed, (uint32_t)(seed >> 32));
             else
                 k2_small<float><<<1, 64, 0, ctx->stream>>>((const float*)d->J, d->bias, d->state, replay_uniforms ? d->uniforms : nullptr,
-                                                           d->samples, n, T, n_burnin, n_sweeps, n_samples, sweep0, tag, (uint32_t)seed,
-                                                           (uint32_t)(seed >> 32));
+                                                           d->samples, n, T, temps_dev, n_burnin, n_sweeps, n_samples, sweep0, tag,
+                                                           (uint32_t)seed, (uint32_t)(seed >> 32));
             TSU_HIP_TRY(ctx, hipGetLastError());
         }
     } else {
         // larger systems: the sweep paths above, one call per recorded state; samples gathered on the device
+        // (with a schedule every recorded state is one sweep: n_burnin == 0 and n_sweeps == 1)
         int rc = tsu_dense_sweep(d, T, n_burnin, order, seed, sweep0, replica, replay_uniforms);
         if (rc != TSU_OK) return rc;
         size_t off = (size_t)n_burnin * n;
         uint32_t sw = sweep0 + (uint32_t)n_burnin;
         for (int k = 0; k < n_samples; ++k) {
-            rc = tsu_dense_sweep(d, T, n_sweeps, order ? order + off : nullptr, seed, sw, replica, replay_uniforms ? replay_uniforms + off : nullptr);
+            rc = tsu_dense_sweep(d, temps ? temps[k] : T, n_sweeps, order ? order + off : nullptr, seed, sw, replica,
+                                 replay_uniforms ? replay_uniforms + off : nullptr);
             if (rc != TSU_OK) return rc;
             TSU_HIP_TRY(ctx, hipMemcpyAsync(d->samples + (size_t)k * n, d->state, (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
             off += (size_t)n_sweeps * n;
@@ -660,6 +680,20 @@ int tsu_dense_sample(tsu_dense* d, double T, int n_burnin, int n_sweeps, int n_s
     if (out_bytes) TSU_HIP_TRY(ctx, hipMemcpyAsync(samples_host, d->samples, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TSU_OK;
+}
+
+int tsu_dense_sample(tsu_dense* d, double T, int n_burnin, int n_sweeps, int n_samples, const int64_t* order, uint64_t seed,
+                     uint32_t sweep0, uint32_t replica, const double* replay_uniforms, int8_t* samples_host) {
+    if (!d) return TSU_E_INVALID;
+    return dense_run(d, T, nullptr, n_burnin, n_sweeps, n_samples, order, seed, sweep0, replica, replay_uniforms, samples_host);
+}
+
+int tsu_dense_anneal(tsu_dense* d, const double* temperatures, int n_steps, const int64_t* order, uint64_t seed, uint32_t sweep0,
+                     uint32_t replica, const double* replay_uniforms, int8_t* states_host) {
+    if (!d) return TSU_E_INVALID;
+    TSU_REQUIRE(d->ctx, n_steps >= 0 && (n_steps == 0 || temperatures), "dense_anneal: need n_steps >= 0 and a temperature per step");
+    for (int s = 0; s < n_steps; ++s) TSU_REQUIRE(d->ctx, temperatures[s] > 0.0, "Temperature must be positive");
+    return dense_run(d, 1.0, temperatures, 0, 1, n_steps, order, seed, sweep0, replica, replay_uniforms, states_host);
 }
 
 int tsu_dense_energy(tsu_dense* d, double* energy) {

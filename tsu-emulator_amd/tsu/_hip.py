@@ -75,6 +75,7 @@ SIGNATURES = {
     "tsu_dense_get_state": (C.c_int, [_vp, _i8p]),
     "tsu_dense_sweep": (C.c_int, [_vp, C.c_double, C.c_int, _i64p, C.c_uint64, C.c_uint32, C.c_uint32, _f64p]),
     "tsu_dense_sample": (C.c_int, [_vp, C.c_double, C.c_int, C.c_int, C.c_int, _i64p, C.c_uint64, C.c_uint32, C.c_uint32, _f64p, _i8p]),
+    "tsu_dense_anneal": (C.c_int, [_vp, _f64p, C.c_int, _i64p, C.c_uint64, C.c_uint32, C.c_uint32, _f64p, _i8p]),
     "tsu_dense_energy": (C.c_int, [_vp, _f64p]),
     "tsu_langevin_create": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)]),
     "tsu_langevin_destroy": (C.c_int, [_vp]),
@@ -346,6 +347,17 @@ class DenseSystem:
         self.ctx.check(self.lib.tsu_dense_sample(self.h, float(T), int(n_burnin), int(n_sweeps), int(n_samples),
                                                  None if o is None else _ptr(o, _i64p), int(seed), int(sweep0), int(replica),
                                                  None if u is None else _ptr(u, _f64p), _ptr(out, _i8p)))
+        return out
+
+    def anneal(self, temperatures, seed=0, sweep0=0, replica=0, order=None, replay_uniforms=None):
+        """One sweep per entry of ``temperatures`` from the resident state, every state recorded: (n_steps, n) int8."""
+        t = np.ascontiguousarray(temperatures, dtype=np.float64)
+        steps = t.size
+        o = None if order is None else np.ascontiguousarray(order, dtype=np.int64).reshape(steps, self.n)
+        u = None if replay_uniforms is None else np.ascontiguousarray(replay_uniforms, dtype=np.float64).reshape(steps, self.n)
+        out = np.empty((steps, self.n), dtype=np.int8)
+        self.ctx.check(self.lib.tsu_dense_anneal(self.h, _ptr(t, _f64p), steps, None if o is None else _ptr(o, _i64p), int(seed),
+                                                 int(sweep0), int(replica), None if u is None else _ptr(u, _f64p), _ptr(out, _i8p)))
         return out
 
     def energy(self):

@@ -278,23 +278,69 @@ class GibbsSampler:
                             T_final: float = 0.1, n_steps: int = 1000,
                             cooling_schedule: str = "exponential") -> Tuple[np.ndarray, float]:
         """Reference: tsu/gibbs.py:340-393 (mutates ``self.config.temperature`` in place, as the reference does)."""
-        n_bits = np.asarray(coupling).shape[0]
+        coupling = np.asarray(coupling)
+        n_bits = coupling.shape[0]
         state = np.random.randint(0, 2, size=n_bits)
+        if cooling_schedule == "exponential":
+            temps = [T_initial * (T_final / T_initial) ** (step / n_steps) for step in range(n_steps)]
+        else:  # linear
+            temps = [T_initial + (T_final - T_initial) * step / n_steps for step in range(n_steps)]
+        if n_bits > self._ANNEAL_HOST_ENERGY_MAX:
+            # large systems: energies by the device reduction, one step at a time
+            best_state = state.copy()
+            best_energy = self.compute_energy(state, coupling, bias)
+            for T in temps:
+                self.config.temperature = T
+                state = self.gibbs_sweep(state, coupling, bias, n_sweeps=1)
+                energy = self.compute_energy(state, coupling, bias)
+                if energy < best_energy:
+                    best_energy = energy
+                    best_state = state.copy()
+            return best_state, best_energy
+        # the whole schedule in one device call (one sweep per temperature, every state recorded); the energies and the
+        # running minimum are evaluated here with the reference's own expression (gibbs.py:233-236), so that ties
+        # between equal-energy states break as they do there
+        bias_arr = None if bias is None else np.asarray(bias)
         best_state = state.copy()
-        best_energy = self.compute_energy(state, coupling, bias)
-        for step in range(n_steps):
-            if cooling_schedule == "exponential":
-                alpha = step / n_steps
-                T = T_initial * (T_final / T_initial) ** alpha
-            else:  # linear
-                T = T_initial + (T_final - T_initial) * step / n_steps
-            self.config.temperature = T
-            state = self.gibbs_sweep(state, coupling, bias, n_sweeps=1)
-            energy = self.compute_energy(state, coupling, bias)
-            if energy < best_energy:
-                best_energy = energy
-                best_state = state.copy()
+        best_energy = self._energy_host(state, coupling, bias_arr)
+        if n_steps > 0:
+            for T in temps:
+                if T <= 0:
+                    raise ValueError("Temperature must be positive")
+            sys = self._system(coupling, bias)
+            sys.set_state(self._as_bits(state, n_bits))
+            random_order = self.config.update_order == "random"
+            if self.rng == "numpy":
+                if random_order:
+                    order = np.empty((n_steps, n_bits), dtype=np.int64)
+                    uni = np.empty((n_steps, n_bits), dtype=np.float64)
+                    for s_ in range(n_steps):
+                        order[s_] = np.random.permutation(n_bits)
+                        uni[s_] = np.random.rand(n_bits)
+                else:
+                    order, uni = None, np.random.rand(n_steps, n_bits)
+                states = sys.anneal(temps, order=order, replay_uniforms=uni)
+            else:
+                order = np.array([np.random.permutation(n_bits) for _ in range(n_steps)]).reshape(n_steps, n_bits) if random_order else None
+                states = sys.anneal(temps, seed=self._philox_seed(), sweep0=self._sweep_counter, order=order)
+                self._sweep_counter += n_steps
+            self.config.temperature = temps[-1]
+            for k in range(n_steps):
+                cand = states[k].astype(state.dtype)
+                energy = self._energy_host(cand, coupling, bias_arr)
+                if energy < best_energy:
+                    best_energy = energy
+                    best_state = cand
         return best_state, best_energy
+
+    _ANNEAL_HOST_ENERGY_MAX = 512  # systems up to this size: energies of the recorded states on the host
+
+    @staticmethod
+    def _energy_host(state: np.ndarray, coupling: np.ndarray, bias: Optional[np.ndarray]) -> float:
+        energy = -0.5 * state.dot(coupling).dot(state)
+        if bias is not None:
+            energy -= bias.dot(state)
+        return float(energy)
 
 
 class HardwareEmulator:
