@@ -124,6 +124,13 @@ int tsu_ising2d_sweep_part(tsu_ising2d* lat, int n_sweeps, uint64_t seed, uint32
  * the row below the slab is included when that row exists).  M = sum_s/N, E = -J*sum_bonds - h*sum_s. */
 int tsu_ising2d_observables(tsu_ising2d* lat, int64_t* sum_s, int64_t* sum_bonds);
 
+/* The sampling loop of IsingModel.sample / GibbsSampler.sample_boltzmann (ising.py:150-181, gibbs.py:203-211) on the
+ * lattice: n_burnin sweeps, then n_samples x (n_sweeps sweeps, record).  samples_host receives n_samples * rows * cols
+ * spins (row-major, no padding).  Sweep numbers count on from sweep0; the states are gathered on the device and cross
+ * PCIe once. */
+int tsu_ising2d_sample(tsu_ising2d* lat, int n_burnin, int n_sweeps, int n_samples, uint64_t seed, uint32_t sweep0,
+                       uint32_t replica, int8_t* samples_host);
+
 /* Many independent lattices at once (one per temperature of a scan, ising.py:424-476; replicas of a tempering
  * ladder): lattice i does n_sweeps sweeps with its own thresholds, seeds[i], sweep0s[i], replicas[i] -- the same
  * results as n calls of tsu_ising2d_sweep.  Lattices that fit the one-workgroup kernel (TSU_KERNEL_SMALL) run as ONE

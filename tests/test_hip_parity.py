@@ -198,6 +198,23 @@ def test_ising2d_sweep_batch_equals_one_by_one(hip, rows, cols, periodic):
         lat.close()
 
 
+@pytest.mark.parametrize("rows,cols,periodic", [(32, 32, False), (130, 36, True), (128, 1024, True)])
+def test_ising2d_sample_run_matches_oracle(hip, rows, cols, periodic):
+    """tsu_ising2d_sample: burn-in + n_samples x n_sweeps with the states gathered on the device == the oracle's chain."""
+    seed, burn, ns, m = 4711, 5, 3, 4
+    table = ora.ising2d_thresholds(1.0, 0.1, 2.4, 0)
+    lat = hip.Lattice(rows, cols, periodic)
+    lat.randomize(seed)
+    lat.set_thresholds(table)
+    got = lat.sample(burn, ns, m, seed, sweep0=2)
+    cur = ora.ising2d_sweep(ora.ising2d_randomize(rows, cols, seed), periodic, table, burn, seed, sweep0=2)
+    for k in range(m):
+        cur = ora.ising2d_sweep(cur, periodic, table, ns, seed, sweep0=2 + burn + k * ns)
+        np.testing.assert_array_equal(got[k], cur)
+    np.testing.assert_array_equal(lat.get_spins(), cur)
+    lat.close()
+
+
 def test_ising2d_argument_errors(hip):
     with pytest.raises(hip.UnsupportedError):
         hip.Lattice(5, 8, True)  # odd periodic dimension has no 2-colouring

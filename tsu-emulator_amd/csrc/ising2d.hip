@@ -681,6 +681,34 @@ int tsu_ising2d_observables(tsu_ising2d* L, int64_t* sum_s, int64_t* sum_bonds) 
     return check_persist_error(L);
 }
 
+int tsu_ising2d_sample(tsu_ising2d* L, int n_burnin, int n_sweeps, int n_samples, uint64_t seed, uint32_t sweep0, uint32_t replica,
+                       int8_t* samples_host) {
+    if (!L) return TSU_E_INVALID;
+    tsu_ctx* ctx = L->ctx;
+    TSU_REQUIRE(ctx, n_burnin >= 0 && n_sweeps > 0 && n_samples >= 0, "ising2d_sample: need n_burnin >= 0, n_sweeps > 0, n_samples >= 0");
+    TSU_REQUIRE(ctx, n_samples == 0 || samples_host, "ising2d_sample: NULL output");
+    TSU_REQUIRE(ctx, L->ghost == 0, "ising2d_sample: whole lattices only (a slab's ghost rows need the exchange between sweeps)");
+    const size_t site_bytes = (size_t)L->rows * (size_t)L->cols, bytes = site_bytes * (size_t)n_samples;
+    int8_t* d_samples = nullptr;
+    if (bytes) TSU_HIP_TRY(ctx, hipMalloc(&d_samples, bytes));
+    int rc = tsu_ising2d_sweep(L, n_burnin, seed, sweep0, replica);
+    uint32_t sw = sweep0 + (uint32_t)n_burnin;
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < n_samples && rc == TSU_OK && e == hipSuccess; ++k) {
+        rc = tsu_ising2d_sweep(L, n_sweeps, seed, sw, replica);
+        sw += (uint32_t)n_sweeps;
+        if (rc == TSU_OK)
+            e = hipMemcpy2DAsync(d_samples + (size_t)k * site_bytes, (size_t)L->cols, L->alloc[L->cur] + (size_t)L->ghost * L->pitch, L->pitch,
+                                 (size_t)L->cols, (size_t)L->rows, hipMemcpyDeviceToDevice, ctx->stream);
+    }
+    if (rc == TSU_OK && e == hipSuccess && bytes) e = hipMemcpyAsync(samples_host, d_samples, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    if (d_samples) (void)hipFree(d_samples);
+    if (rc != TSU_OK) return rc;
+    if (e != hipSuccess || e2 != hipSuccess) return tsu_fail(ctx, TSU_E_HIP, "ising2d_sample: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    return check_persist_error(L);
+}
+
 int tsu_ising2d_sweep_batch(tsu_ising2d* const* lats, int n_lats, int n_sweeps, const uint64_t* seeds, const uint32_t* sweep0s,
                             const uint32_t* replicas) {
     if (!lats || n_lats < 1 || !lats[0]) return TSU_E_INVALID;

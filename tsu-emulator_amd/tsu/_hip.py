@@ -63,6 +63,7 @@ SIGNATURES = {
     "tsu_ising2d_sweep": (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32]),
     "tsu_ising2d_sweep_part": (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]),
     "tsu_ising2d_observables": (C.c_int, [_vp, _i64p, _i64p]),
+    "tsu_ising2d_sample": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, _i8p]),
     "tsu_ising2d_sweep_batch": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
                                           C.POINTER(C.c_uint32)]),
     "tsu_ising2d_observables_batch": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
@@ -250,6 +251,13 @@ class Lattice:
 
     def sweep_part(self, n_sweeps, seed, sweep0, part, replica=0):
         self.ctx.check(self.lib.tsu_ising2d_sweep_part(self.h, int(n_sweeps), int(seed), int(sweep0), int(replica), int(part)))
+
+    def sample(self, n_burnin, n_sweeps, n_samples, seed, sweep0=0, replica=0):
+        """n_burnin sweeps, then n_samples x (n_sweeps sweeps, record): (n_samples, rows, cols) int8, one PCIe transfer."""
+        out = np.empty((int(n_samples), self.rows, self.cols), dtype=np.int8)
+        self.ctx.check(self.lib.tsu_ising2d_sample(self.h, int(n_burnin), int(n_sweeps), int(n_samples), int(seed), int(sweep0),
+                                                   int(replica), _ptr(out, _i8p)))
+        return out
 
     def observables(self):
         a, b = C.c_int64(0), C.c_int64(0)

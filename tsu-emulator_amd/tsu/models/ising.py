@@ -284,14 +284,20 @@ class IsingGrid(IsingModel):
             lat.set_spins((2 * bits - 1).astype(np.int8).reshape(self.rows, self.cols))
         self._set_model(lat)
         seed = self._philox_seed()
-        lat.sweep(int(cfg.n_burnin), seed, self._sweep_counter)
-        self._sweep_counter += int(cfg.n_burnin)
         samples = np.zeros((n_samples, self.n_spins), dtype=int)
-        for i in range(n_samples):
-            lat.sweep(int(cfg.n_sweeps), seed, self._sweep_counter)
-            self._sweep_counter += int(cfg.n_sweeps)
-            samples[i] = lat.get_spins().reshape(-1)
-            self.sampler.sample_count += 1
+        # burn-in and the n_samples x n_sweeps loop in as few device calls as a 1 GiB staging buffer allows
+        chunk = max(1, min(int(n_samples), (1 << 30) // max(1, self.n_spins)))
+        done, burn = 0, int(cfg.n_burnin)
+        if n_samples == 0:
+            lat.sweep(burn, seed, self._sweep_counter)
+            self._sweep_counter += burn
+        while done < n_samples:
+            m = min(chunk, n_samples - done)
+            samples[done:done + m] = lat.sample(burn, int(cfg.n_sweeps), m, seed, self._sweep_counter).reshape(m, -1)
+            self._sweep_counter += burn + m * int(cfg.n_sweeps)
+            self.sampler.sample_count += m
+            done += m
+            burn = 0
         return samples
 
     def energy(self, state: np.ndarray) -> float:
