@@ -357,6 +357,21 @@ def test_dense_sample_run_matches_oracle(hip, n):
     d.close()
 
 
+def test_dense_long_run_stays_on_the_oracle_chain(hip):
+    """Soak for the cooperative kernel's barrier / agent-scope data path: 200 sweeps of a 5000-site glass (two
+    superblocks, ~4000 grid barriers, fields handed on between sweeps) in ONE call stay bit-identical to the oracle."""
+    n, T = 5000, 0.7
+    rng = np.random.default_rng(5)
+    J = rng.standard_normal((n, n)).astype(np.float32).astype(np.float64) / np.sqrt(n)
+    J = (J + J.T) / 2
+    st = rng.integers(0, 2, size=n).astype(np.int8)
+    d = hip.DenseSystem(J, None, hip.DTYPE_F64)
+    d.set_state(st)
+    d.sweep(T, 200, seed=3, sweep0=0)
+    np.testing.assert_array_equal(d.get_state(), ora.dense_sweep_philox(st, J, None, T, 200, 3, sweep0=0))
+    d.close()
+
+
 def test_dense_golden_replay_on_device(hip, golden):
     """The reference's own seeded run (tests/golden/g1, g2) reproduced by the HIP kernel with replayed MT19937 draws."""
     for name in ("g1_dense_sequential", "g2_dense_random"):
