@@ -231,7 +231,16 @@ class GibbsSampler:
                            n_samples: int = 1000, swap_interval: int = 10) -> Tuple[np.ndarray, dict]:
         """Reference: tsu/gibbs.py:238-338 (replica exchange; swap rule :317-323)."""
         n_replicas = len(temperatures)
-        n_bits = np.asarray(coupling).shape[0]
+        coupling = np.asarray(coupling)
+        n_bits = coupling.shape[0]
+        bias_arr = None if bias is None else np.asarray(bias)
+        if n_bits <= self._ANNEAL_HOST_ENERGY_MAX:
+            # small systems: the reference's own expression on the host instead of a device round trip per energy
+            def energy_of(s):
+                return self._energy_host(np.asarray(s), coupling, bias_arr)
+        else:
+            def energy_of(s):
+                return self.compute_energy(s, coupling, bias)
         states = [np.random.randint(0, 2, size=n_bits) for _ in range(n_replicas)]
         samplers = []
         for T in temperatures:
@@ -250,12 +259,12 @@ class GibbsSampler:
         while len(samples) < n_samples:
             for i, sampler in enumerate(samplers):
                 states[i] = sampler.gibbs_sweep(states[i], coupling, bias, n_sweeps=self.config.n_sweeps)
-                energies_history[i].append(self.compute_energy(states[i], coupling, bias))
+                energies_history[i].append(energy_of(states[i]))
             sweep_count += 1
             if sweep_count % swap_interval == 0:
                 for i in range(n_replicas - 1):
-                    E_i = self.compute_energy(states[i], coupling, bias)
-                    E_j = self.compute_energy(states[i + 1], coupling, bias)
+                    E_i = energy_of(states[i])
+                    E_j = energy_of(states[i + 1])
                     delta = (1.0 / temperatures[i] - 1.0 / temperatures[i + 1]) * (E_j - E_i)
                     swap_attempts += 1
                     if delta >= 0 or np.random.rand() < np.exp(delta):
