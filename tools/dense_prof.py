@@ -11,3 +11,4 @@ d = hip.DenseSystem(J, None, hip.DTYPE_F32, ctx=ctx)
 d.set_state(rng.integers(0, 2, size=n).astype(np.int8))
 d.sweep(1.0, 3, seed=1, sweep0=0)
 ctx.synchronize()
+d.close()
