@@ -5,6 +5,7 @@ present, every operation that needs it raises :class:`HipUnavailableError`.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -180,7 +181,7 @@ class Context:
 
     def __del__(self):
         try:
-            if getattr(self, "h", None):
+            if getattr(self, "h", None) and not sys.is_finalizing():
                 self.lib.tsu_shutdown(self.h)
                 self.h = None
         except Exception:
@@ -216,7 +217,9 @@ class Lattice:
             self.lib.tsu_ising2d_destroy(self.h)
             self.h = None
 
-    __del__ = close
+    def __del__(self):
+        if not sys.is_finalizing():  # at interpreter exit the process teardown frees the device memory
+            self.close()
 
     def set_spins(self, spins, row_first=0):
         s = np.ascontiguousarray(spins, dtype=np.int8).reshape(-1, self.cols)
@@ -327,7 +330,9 @@ class DenseSystem:
             self.lib.tsu_dense_destroy(self.h)
             self.h = None
 
-    __del__ = close
+    def __del__(self):
+        if not sys.is_finalizing():  # at interpreter exit the process teardown frees the device memory
+            self.close()
 
     def set_state(self, bits):
         b = np.ascontiguousarray(bits, dtype=np.int8).reshape(self.n)
@@ -390,7 +395,9 @@ class LangevinChains:
             self.lib.tsu_langevin_destroy(self.h)
             self.h = None
 
-    __del__ = close
+    def __del__(self):
+        if not sys.is_finalizing():  # at interpreter exit the process teardown frees the device memory
+            self.close()
 
     def set_state(self, x):
         xx = np.ascontiguousarray(np.broadcast_to(np.asarray(x, dtype=np.float32), (self.n_chains, self.dim)))
