@@ -1,4 +1,4 @@
-// dense_coop.hip -- K2 in ONE cooperative launch per call: natural-order sequential Gibbs sweeps on a dense J.
+// dense_coop.hip -- K2 in ONE launch of a co-resident grid per call: natural-order sequential Gibbs sweeps on a dense J.
 //
 // Same mathematics as the superblock path in dense.hip (the sequential pass over a superblock of SB_SIZE positions is
 // the unique fixed point of delta = decide(f + L delta), reached exactly by Jacobi iteration from delta = 0), but
@@ -453,9 +453,24 @@ static int coop_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint3
     int grid = ctx->cus;
     const int useful = (n + CO_THREADS / 64 - 1) / (CO_THREADS / 64);
     if (grid > useful) grid = useful;
-    void* args[] = {&P};
-    hipError_t e = hipLaunchCooperativeKernel((const void*)kern, dim3((unsigned)grid), dim3(CO_THREADS), args, (unsigned)lds_bytes, ctx->stream);
-    if (e != hipSuccess) {  // no cooperative launch on this device / configuration: not an error, use the other path
+    // The grid is one workgroup per CU at most and fits the device (occupancy query above), so an ordinary launch makes
+    // all workgroups resident unless another process holds CUs for good; the bounded wait in the barrier turns that
+    // case into the fallback below instead of a hang.  TSU_K2_COOP_LAUNCH=1 asks the runtime for a cooperative launch
+    // instead (same kernel; rocprofv3 crashes at process exit after profiling one, hence not the default).
+    static int coop_api = -1;
+    if (coop_api < 0) {
+        const char* ev = getenv("TSU_K2_COOP_LAUNCH");
+        coop_api = ev ? atoi(ev) : 0;
+    }
+    hipError_t e;
+    if (coop_api) {
+        void* args[] = {&P};
+        e = hipLaunchCooperativeKernel((const void*)kern, dim3((unsigned)grid), dim3(CO_THREADS), args, (unsigned)lds_bytes, ctx->stream);
+    } else {
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(CO_THREADS), lds_bytes, ctx->stream, P);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) {  // launch not possible in this configuration: not an error, use the other path
         (void)hipGetLastError();
         d->co_disabled = 1;
         return TSU_OK;
@@ -463,7 +478,14 @@ static int coop_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint3
     unsigned h[4];  // [1] = error flag, [2] = slowest fixed point, [3] = not-converged flag
     TSU_HIP_TRY(ctx, hipMemcpyAsync(h + 1, d->co_bar + BAR_ERR, 3 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
     TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (h[1]) return tsu_fail(ctx, TSU_E_HIP, "dense_sweep: grid barrier timed out (cooperative kernel not co-resident?); state invalid");
+    if (h[1]) {
+        // a workgroup waited 4 s at a barrier: the grid was not co-resident (GPU shared with another long-running
+        // kernel).  The caller restores the state from its backup and continues on the one-launch-per-iteration path.
+        fprintf(stderr, "[tsu] dense sweep: grid barrier timed out (GPU shared?); continuing with one launch per iteration\n");
+        d->co_disabled = 1;
+        if (d_tl) (void)hipFree(d_tl);
+        return TSU_OK;
+    }
     if (d_tl) {
         unsigned long long tl[8];
         (void)hipMemcpy(tl, d_tl, sizeof(tl), hipMemcpyDeviceToHost);
