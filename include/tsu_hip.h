@@ -146,6 +146,8 @@ int tsu_ising2d_row_ptr(tsu_ising2d* lat, int local_row, void** device_ptr, size
  * tsu_ising2d_last_sweep_ms returns the milliseconds of the most recent tsu_ising2d_sweep (HIP events; synchronises). */
 int tsu_ising2d_set_timing(tsu_ising2d* lat, int enable);
 int tsu_ising2d_last_sweep_ms(tsu_ising2d* lat, float* ms);
+/* sweep-kernel launches issued for this lattice so far (a tile-resident launch runs many generations of sweeps) */
+int tsu_ising2d_launch_count(tsu_ising2d* lat, uint64_t* n_launches);
 
 /* ------------------------------------------------------------------ dense coupling matrix (K2)
  * Replaces GibbsSampler.gibbs_sweep / sample_boltzmann / compute_energy on a dense J

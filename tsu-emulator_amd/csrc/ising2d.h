@@ -19,9 +19,12 @@ struct tsu_ising2d {
     int64_t* d_obs;      // 2 x int64 accumulators
     hipEvent_t ev0, ev1;
     int timed, timing;
-    int* d_sync;         // persistent kernel: [0] ticket, [1..] per-tile generation counters
+    unsigned long long launches;  // sweep-kernel launches so far
+    int* d_sync;         // tile-resident kernel: per-tile generation counters
+    uint64_t* d_xbuf;    // tile-resident kernel: exchange strips
+    size_t xbuf_cap;
     size_t sync_cap;     // ints allocated in d_sync
-    int* h_err;          // host-mapped flag the persistent kernel sets if a bounded wait expires
+    int* h_err;          // host-mapped flag the tile-resident kernel sets if a bounded wait expires
 };
 
 

@@ -442,7 +442,10 @@ int tsu_ising2d_create_slab(tsu_ctx* ctx, int64_t total_rows, int cols, int peri
     L->d_obs = nullptr;
     L->timed = 0;
     L->timing = 0;
+    L->launches = 0;
     L->d_sync = nullptr;
+    L->d_xbuf = nullptr;
+    L->xbuf_cap = 0;
     L->sync_cap = 0;
     L->h_err = nullptr;
     size_t bytes = (size_t)(rows + 2 * ghost) * L->pitch;
@@ -474,6 +477,7 @@ int tsu_ising2d_destroy(tsu_ising2d* L) {
         if (L->alloc[i]) (void)hipFree(L->alloc[i]);
     if (L->d_obs) (void)hipFree(L->d_obs);
     if (L->d_sync) (void)hipFree(L->d_sync);
+    if (L->d_xbuf) (void)hipFree(L->d_xbuf);
     if (L->h_err) (void)hipHostFree(L->h_err);
     (void)hipEventDestroy(L->ev0);
     (void)hipEventDestroy(L->ev1);
@@ -498,7 +502,7 @@ int tsu_ising2d_set_spins(tsu_ising2d* L, const int8_t* host, int row_first, int
 static int check_persist_error(tsu_ising2d* L) {
     if (L->h_err && *L->h_err) {
         *L->h_err = 0;
-        return tsu_fail(L->ctx, TSU_E_HIP, "ising2d: persistent sweep kernel timed out waiting for a neighbouring tile (results invalid)");
+        return tsu_fail(L->ctx, TSU_E_HIP, "ising2d: tile-resident sweep kernel timed out waiting for a neighbouring tile (GPU shared?); results invalid");
     }
     return TSU_OK;
 }
@@ -613,6 +617,7 @@ int tsu_ising2d_sweep_part(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_t
             attr_set = true;
         }
         k1_small<<<1, threads, lds_bytes, ctx->stream>>>(p, tbl, sweep0, n_sweeps);
+        L->launches += 1;
         TSU_HIP_TRY(ctx, hipGetLastError());
     } else if (use_tiled) {
         int rc = tsu_ising2d_tiled_sweep(L, n_sweeps, seed, sweep0, replica, part);
@@ -638,6 +643,7 @@ int tsu_ising2d_sweep_part(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_t
                 p.r_hi = L->rows + (ext_bot > 0 ? ext_bot : 0);
                 p.hs = 2u * (sweep0 + (uint32_t)s) + (uint32_t)colour;
                 k1_generic<<<grid_for(L, p.r_hi - p.r_lo), dim3(64, 4, 1), 0, ctx->stream>>>(p, tbl, colour);
+                L->launches += 1;
             }
         TSU_HIP_TRY(ctx, hipGetLastError());
     }
@@ -652,6 +658,12 @@ int tsu_ising2d_set_timing(tsu_ising2d* L, int enable) {
     if (!L) return TSU_E_INVALID;
     L->timing = enable != 0;
     L->timed = 0;
+    return TSU_OK;
+}
+
+int tsu_ising2d_launch_count(tsu_ising2d* L, uint64_t* n) {
+    if (!L || !n) return TSU_E_INVALID;
+    *n = L->launches;
     return TSU_OK;
 }
 

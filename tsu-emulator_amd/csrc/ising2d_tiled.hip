@@ -252,10 +252,30 @@ static __device__ __forceinline__ void sweep_pairs(const Rows2Ctx& c, const Phil
 }
 
 // one tile: HBM -> LDS planes, 2k half-sweeps, interior -> HBM (the other buffer)
-template <int HT, int WO, int THREADS, bool OPEN = false>
+// Tile-resident generations (RESIDENT): when every tile of the lattice has its own workgroup on the chip at the same
+// time, a tile stays in LDS for many generations of k sweeps; after each generation it publishes the 2k interior rows
+// at its top and bottom and its first and last interior octet column (the colour planes as they are, ~20 KB) to a
+// global exchange buffer, raises its generation flag, waits for its eight neighbours' flags and refreshes its halo
+// from their strips.  The full-tile stage and store (87 + 64 KB per generation) and the launch gap
+// happen once per call instead of once per generation.
+// The strips travel through agent-scope relaxed atomic stores and loads (performed at the device's coherence point,
+// past the per-CU L1 and the per-XCD L2, like dense_coop.hip's shared data), so no cache write-back / invalidate is
+// needed around the flags: with release/acquire fences the publish step alone cost 5 us per generation.
+static __device__ __forceinline__ void xst(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static __device__ __forceinline__ uint64_t xld(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct ResidentParams {
+    uint64_t* xbuf;  // [2 parities][tiles][XSTRIDE] exchange strips
+    int* done;       // [tiles] generations published
+    int* err;        // host-mapped: set if a bounded wait expired (results invalid)
+    int n_gen, k_last, tiles_y;
+    long long* dbg;  // TSU_K1_VERBOSE=2: wall_clock64 ticks of tile 0 spent in [sweeps, publish, wait, fetch]
+};
+
+template <int HT, int WO, int THREADS, bool OPEN = false, bool RESIDENT = false>
 static __device__ __forceinline__ void tile_body(const TiledParams& p, const int8_t* __restrict__ src, int8_t* __restrict__ dst,
                                                  const int k, const uint32_t sweep0, const int tx, const int ty, uint64_t* lds,
-                                                 const PhiloxKeys& K) {
+                                                 const PhiloxKeys& K, const ResidentParams* R = nullptr) {
     constexpr int NO = WO + 2;
     constexpr int RLMAX = THREADS / NO;
     const int H = p.tile_h;
@@ -346,10 +366,27 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
     asm volatile("v_mov_b32 %0, %1" : "=v"(c.tblL0) : "s"(p.tblL0));
     asm volatile("v_mov_b32 %0, %1" : "=v"(c.tblL1) : "s"(p.tblL1));
 
-    for (int hsi = 0; hsi < 2 * k; ++hsi) {
+    const int n_gen = RESIDENT ? R->n_gen : 1;
+    long long tl0 = 0, tl[4] = {0, 0, 0, 0};
+    const bool timing = RESIDENT && R->dbg && blockIdx.x == 0 && tid == 0;
+    if (timing) tl0 = wall_clock64();
+#define RES_MARK(q)                         \
+    if (timing) {                           \
+        const long long now_ = wall_clock64(); \
+        tl[q] += now_ - tl0;                \
+        tl0 = now_;                         \
+    }
+    // RESIDENT: "a neighbour wait expired in this workgroup" -- kept in the guard octet in front of plane 0 (only ever read
+    // as "octet -1" padding): a static __shared__ word would push a 160 KB workgroup past the CU's LDS
+    volatile int& s_fail = *reinterpret_cast<volatile int*>(lds);
+    if (RESIDENT && tid == 0) s_fail = 0;
+    for (int gen = 0; gen < n_gen; ++gen) {
+    const int kg = (RESIDENT && gen == n_gen - 1) ? R->k_last : k;  // sweeps of this generation (the tile keeps TR = H + 4k)
+    const uint32_t sweep_g = sweep0 + (uint32_t)(gen * k);
+    for (int hsi = 0; hsi < 2 * kg; ++hsi) {
         __syncthreads();
         const int kappa = hsi & 1;
-        c.hs = 2u * (sweep0 + (uint32_t)(hsi >> 1)) + (uint32_t)kappa;
+        c.hs = 2u * (sweep_g + (uint32_t)(hsi >> 1)) + (uint32_t)kappa;
         c.Pd = kappa ? plane1 : plane0;
         c.Ps = kappa ? plane0 : plane1;
         c.tr_lo = 1 + hsi;
@@ -372,7 +409,84 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
         }
     }
     __syncthreads();
-
+    RES_MARK(0);
+    if (RESIDENT && gen + 1 < n_gen) {
+        // ---- publish this generation's boundary strips, then refresh the halo from the neighbours' strips
+        const int tiles_x = p.tiles_x, tiles_y = R->tiles_y, ntiles = tiles_x * tiles_y;
+        const int me = ty * tiles_x + tx;
+        const int n_tb = 2 * k * WO, n_lr = H;                  // elements per plane of a top/bottom and a left/right strip
+        const int xstride = 4 * n_tb + 4 * n_lr;                 // TOP[2][n_tb] BOTTOM[2][n_tb] LEFT[2][n_lr] RIGHT[2][n_lr]
+        uint64_t* mine = R->xbuf + ((size_t)(gen & 1) * ntiles + me) * xstride;
+        for (int i = tid; i < 2 * n_tb; i += THREADS) {
+            const int pl = i / n_tb, rem = i - pl * n_tb, r = rem / WO, o = rem - r * WO;
+            const uint64_t* P = pl ? plane1 : plane0;
+            xst(mine + i, P[(2 * k + r) * NO + 1 + o]);           // TOP: first 2k interior rows
+            xst(mine + 2 * n_tb + i, P[(H + r) * NO + 1 + o]);    // BOTTOM: last 2k interior rows
+        }
+        for (int i = tid; i < 2 * n_lr; i += THREADS) {
+            const int pl = i / n_lr, r = i - pl * n_lr;
+            const uint64_t* P = pl ? plane1 : plane0;
+            xst(mine + 4 * n_tb + i, P[(2 * k + r) * NO + 1]);             // LEFT: first interior octet
+            xst(mine + 4 * n_tb + 2 * n_lr + i, P[(2 * k + r) * NO + WO]); // RIGHT: last interior octet
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(R->done + me, gen + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        RES_MARK(1);
+        const int txl = tx == 0 ? tiles_x - 1 : tx - 1, txr = tx == tiles_x - 1 ? 0 : tx + 1;
+        const int tyu = ty == 0 ? tiles_y - 1 : ty - 1, tyd = ty == tiles_y - 1 ? 0 : ty + 1;
+        if (tid < 8) {  // the eight neighbours (periodic in tiles), one lane each
+            const int nx = (tid == 0 || tid == 3 || tid == 5) ? txl : ((tid == 2 || tid == 4 || tid == 7) ? txr : tx);
+            const int ny = tid < 3 ? tyu : (tid < 5 ? ty : tyd);
+            const int* flag = R->done + ny * tiles_x + nx;
+            int spins = 0;
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen + 1) {
+                __builtin_amdgcn_s_sleep(2);
+                // the error flag lives in host memory (a PCIe round trip): look at it rarely
+                if (++spins > (1 << 23) || ((spins & 0xFFF) == 0 && __hip_atomic_load(R->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))) {
+                    __hip_atomic_store(R->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // ~seconds: grid not co-resident
+                    s_fail = 1;
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        if (s_fail) return;  // nothing is stored: the source buffer stays valid
+        RES_MARK(2);
+        const uint64_t* xg = R->xbuf + (size_t)(gen & 1) * ntiles * xstride;
+        const uint64_t* X_u = xg + (size_t)(tyu * tiles_x + tx) * xstride;
+        const uint64_t* X_d = xg + (size_t)(tyd * tiles_x + tx) * xstride;
+        const uint64_t* X_l = xg + (size_t)(ty * tiles_x + txl) * xstride;
+        const uint64_t* X_r = xg + (size_t)(ty * tiles_x + txr) * xstride;
+        const uint64_t* X_ul = xg + (size_t)(tyu * tiles_x + txl) * xstride;
+        const uint64_t* X_ur = xg + (size_t)(tyu * tiles_x + txr) * xstride;
+        const uint64_t* X_dl = xg + (size_t)(tyd * tiles_x + txl) * xstride;
+        const uint64_t* X_dr = xg + (size_t)(tyd * tiles_x + txr) * xstride;
+        // halo rows: top [0, 2k) from the BOTTOM strips above, bottom [2k + H, TR) from the TOP strips below
+        for (int i = tid; i < 2 * 2 * k * NO; i += THREADS) {
+            const int pl = i / (2 * k * NO), rem = i - pl * (2 * k * NO), r = rem / NO, o = rem - r * NO;
+            uint64_t* P = pl ? plane1 : plane0;
+            const int e = pl * n_tb + r * WO;
+            const uint64_t* pu = o == 0 ? X_ul + 2 * n_tb + e + WO - 1 : (o == NO - 1 ? X_ur + 2 * n_tb + e : X_u + 2 * n_tb + e + o - 1);
+            const uint64_t* pd = o == 0 ? X_dl + e + WO - 1 : (o == NO - 1 ? X_dr + e : X_d + e + o - 1);
+            const uint64_t up = xld(pu), dn = xld(pd);
+            P[r * NO + o] = up;
+            P[(2 * k + H + r) * NO + o] = dn;
+        }
+        // halo octets of the interior rows: octet 0 from the left neighbour's RIGHT strip, octet NO-1 from the right one's LEFT
+        for (int i = tid; i < 2 * n_lr; i += THREADS) {
+            const int pl = i / n_lr, r = i - pl * n_lr;
+            uint64_t* P = pl ? plane1 : plane0;
+            const uint64_t vl = xld(X_l + 4 * n_tb + 2 * n_lr + i), vr = xld(X_r + 4 * n_tb + i);
+            P[(2 * k + r) * NO] = vl;
+            P[(2 * k + r) * NO + NO - 1] = vr;
+        }
+        RES_MARK(3);
+    }
+    }  // generations
+    if (timing)
+        for (int q = 0; q < 4; ++q) R->dbg[q] = tl[q];
+#undef RES_MARK
     // interior octets are tile columns 1 .. NO-2: the same thread -> column mapping, halo columns idle
     if (p.debug < 2 && al < RLMAX && oct >= 1 && oct <= WO && q0 + oct - 1 < p.nchunks) {
         int8_t* col = dst + 16 * (long long)(q0 + oct - 1);
@@ -403,78 +517,18 @@ __global__ __launch_bounds__(THREADS, MINW) void k1_tiled2(TiledParams p) {
                                     p.ty_first + (blockIdx.x / p.tiles_x) * p.ty_stride, lds, K);
 }
 
-// ------------------------------------------------------------------ persistent multi-generation kernel
-// One launch runs n_gen generations of k sweeps each over a whole periodic lattice (no slabs).  Work items are
-// (generation g, tile t), handed out by a global ticket counter in that order.  Item (g, t) reads buffer g & 1 and
-// writes buffer (g + 1) & 1; it may start once the 3 x 3 neighbourhood of t has finished generation g - 1, which is
-// also exactly the condition under which nobody still reads the region it will overwrite.  A workgroup only ever
-// waits for items with smaller tickets, which are finished or held by running workgroups: no deadlock for any grid
-// size.  Hand-off = the guide's release/acquire protocol: stores -> every wave s_waitcnt vmcnt(0) -> barrier ->
-// lane 0 agent release fence -> relaxed agent store of done[t]; consumer: relaxed agent polls (bounded) -> agent
-// acquire fence -> barrier -> plain loads.  This removes the launch gaps and the load-burst / tail of every launch.
-struct PersistParams {
-    TiledParams t;       // per-launch constants; src / dst / k / sweep0 are set per generation
-    int8_t* buf[2];      // owned row 0 of the two lattice buffers; generation g reads buf[(first + g) & 1]
-    int first;
-    int n_gen, k_last;   // generations of t.k sweeps, the last one of k_last sweeps
-    int tiles_y;
-    int* ticket;         // zeroed before the launch
-    int* done;           // [tiles]: number of generations finished, zeroed before the launch
-    int* err;            // set to 1 if a bounded wait expired
+// ------------------------------------------------------------------ tile-resident multi-generation kernel
+struct ResidentLaunch {
+    TiledParams t;
+    ResidentParams r;
 };
 
 template <int H, int WO, int THREADS, int MINW = 1>
-__global__ __launch_bounds__(THREADS, MINW) void k1_persist(PersistParams P) {
+__global__ __launch_bounds__(THREADS, MINW) void k1_resident(ResidentLaunch P) {
     extern __shared__ uint64_t lds[];
-    // the ticket is broadcast through the guard octet in front of plane 0 (only ever read as "octet -1" padding):
-    // a separate static __shared__ word would push two 80 KB workgroups past the CU's 160 KB
-    volatile int* s_ticket = reinterpret_cast<volatile int*>(lds);
     const PhiloxKeys K = make_keys(P.t.k0, P.t.k1);
-    const int ntiles = P.t.tiles_x * P.tiles_y;
-    const int total = ntiles * P.n_gen;
-    const int tid = threadIdx.x;
-    while (true) {
-        __syncthreads();  // the previous tile's store phase has finished reading the LDS planes / s_ticket
-        if (tid == 0) *s_ticket = __hip_atomic_fetch_add(P.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        const int ticket = *s_ticket;
-        if (ticket >= total) break;
-        const int g = ticket / ntiles, t = ticket - g * ntiles;
-        const int tx = t % P.t.tiles_x, ty = t / P.t.tiles_x;
-        if (g > 0) {
-            // wait until the 3 x 3 neighbourhood (periodic in tiles) has finished generation g - 1
-            if (tid < 9) {
-                int nx = tx + (tid % 3) - 1, ny = ty + (tid / 3) - 1;
-                nx = nx < 0 ? nx + P.t.tiles_x : (nx >= P.t.tiles_x ? nx - P.t.tiles_x : nx);
-                ny = ny < 0 ? ny + P.tiles_y : (ny >= P.tiles_y ? ny - P.tiles_y : ny);
-                const int* flag = P.done + ny * P.t.tiles_x + nx;
-                int spins = 0;
-                while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1 << 22)) {  // ~seconds: never reached unless the protocol is broken
-                        __hip_atomic_store(P.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
-                }
-            }
-            if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __syncthreads();
-        }
-        const int par = (P.first + g) & 1;
-        tile_body<H, WO, THREADS>(P.t, par ? P.buf[1] : P.buf[0], par ? P.buf[0] : P.buf[1], g == P.n_gen - 1 ? P.k_last : P.t.k,
-                                  P.t.sweep0 + (uint32_t)(g * P.t.k), tx, ty, lds, K);
-        // publish: this tile's stores are complete and visible before done[t] says so
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(P.done + t, g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    tile_body<H, WO, THREADS, false, true>(P.t, P.t.src, P.t.dst, P.t.k, P.t.sweep0, blockIdx.x % P.t.tiles_x, blockIdx.x / P.t.tiles_x,
+                                          lds, K, &P.r);
 }
 
 // ------------------------------------------------------------------ host side
@@ -484,7 +538,7 @@ constexpr int KMAX = 8;  // one halo octet (16 columns) covers 2k <= 16 half-swe
 struct TileVariant {
     int H, WO, threads;
     void (*kernel)(TiledParams);
-    void (*persist)(PersistParams);  // multi-generation form (nullptr: not built for this shape)
+    void (*resident)(ResidentLaunch);  // tile-resident multi-generation form (nullptr: not built for this shape)
     void (*open)(TiledParams);       // open-boundary form (nullptr: not built for this shape)
 };
 // tile shapes compiled in; TSU_TILE_VARIANT (env, development aid) or tsu_ising2d_set_kernel picks one
@@ -495,20 +549,20 @@ const TileVariant kVariants[] = {
     {64, 64, 512, k1_tiled2<64, 64, 512>},
     {32, 32, 256, k1_tiled2<32, 32, 256>},
     {128, 32, 1024, k1_tiled2<128, 32, 1024>},
-    {64, 32, 512, k1_tiled2<64, 32, 512>, k1_persist<64, 32, 512>, k1_tiled2<64, 32, 512, 1, true>},    // 6
+    {64, 32, 512, k1_tiled2<64, 32, 512>, k1_resident<64, 32, 512>, k1_tiled2<64, 32, 512, 1, true>},    // 6
     {64, 32, 256, k1_tiled2<64, 32, 256>},    // 7
-    {128, 32, 512, k1_tiled2<128, 32, 512>, k1_persist<128, 32, 512>, k1_tiled2<128, 32, 512, 1, true>},  // 8
-    {128, 32, 1024, k1_tiled2<128, 32, 1024>, k1_persist<128, 32, 1024>, k1_tiled2<128, 32, 1024, 1, true>},// 9
+    {128, 32, 512, k1_tiled2<128, 32, 512>, k1_resident<128, 32, 512>, k1_tiled2<128, 32, 512, 1, true>},  // 8
+    {128, 32, 1024, k1_tiled2<128, 32, 1024>, k1_resident<128, 32, 1024>, k1_tiled2<128, 32, 1024, 1, true>},// 9
     {64, 32, 1024, k1_tiled2<64, 32, 1024>},  // 10
     {64, 32, 576, k1_tiled2<64, 32, 576>},    // 11
     {128, 32, 640, k1_tiled2<128, 32, 640>},  // 12
     {128, 32, 832, k1_tiled2<128, 32, 832>},  // 13
     {96, 32, 512, k1_tiled2<96, 32, 512>},    // 14
     {96, 32, 768, k1_tiled2<96, 32, 768>},    // 15
-    {64, 32, 512, k1_tiled2<64, 32, 512, 6>, k1_persist<64, 32, 512, 6>},   // 16: <= 80 VGPRs -> 3 workgroups per CU
+    {64, 32, 512, k1_tiled2<64, 32, 512, 6>, nullptr},   // 16: <= 80 VGPRs -> 3 workgroups per CU
     {64, 32, 512, k1_tiled2<64, 32, 512, 8>},   // 17: <= 64 VGPRs -> 4 workgroups per CU (LDS permitting)
     {64, 32, 256, k1_tiled2<64, 32, 256, 8>},   // 18
-    {128, 32, 512, k1_tiled2<128, 32, 512, 6>, k1_persist<128, 32, 512, 6>}, // 19
+    {128, 32, 512, k1_tiled2<128, 32, 512, 6>, nullptr}, // 19
     {128, 32, 768, k1_tiled2<128, 32, 768, 6>}, // 20: 12 waves per workgroup, 2 workgroups per CU = 6 waves/SIMD
     {128, 32, 640, k1_tiled2<128, 32, 640, 5>}, // 21
     {256, 32, 1024, k1_tiled2<256, 32, 1024, 4>, nullptr, k1_tiled2<256, 32, 1024, 4, true>}, // 22: one 148 KB workgroup per CU
@@ -638,68 +692,87 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
         TSU_HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[&tv - kVariants][p.open] = true;
     }
-    static int use_persist = -1;
-    if (use_persist < 0) {
-        // measured (profiles/r01_persistent_vs_launches.txt): the release/acquire hand-offs cost about what the launch
-        // gaps and load bursts cost, so one launch per generation stays the default; opt in with TSU_K1_PERSIST=1
-        const char* e = getenv("TSU_K1_PERSIST");
-        use_persist = e ? atoi(e) : 0;
+    static int use_resident = -1;
+    if (use_resident < 0) {
+        const char* e = getenv("TSU_K1_RESIDENT");
+        use_resident = e ? atoi(e) : 1;
     }
-    if (use_persist && tv.persist && L->periodic && L->wrap_rows && part == TSU_PART_ALL && n_sweeps > kmax && !p.debug) {
-        // ---- one persistent launch for all generations (whole periodic lattice on this GPU)
+    const int ntiles = p.tiles_x * tiles_y;
+    if (use_resident && tv.resident && L->periodic && L->wrap_rows && part == TSU_PART_ALL && n_sweeps > kmax && !p.debug &&
+        L->rows % TILE_H == 0 && p.nchunks % TILE_WO == 0) {
+        // ---- tile-resident generations: every tile has its own workgroup on the chip for the whole call
         const int vi = (int)(&tv - kVariants);
-        const int ntiles = p.tiles_x * tiles_y;
-        const size_t need = (size_t)ntiles + 1;
-        if (L->sync_cap < need) {
-            if (L->d_sync) (void)hipFree(L->d_sync);
-            L->d_sync = nullptr;
-            L->sync_cap = 0;
-            TSU_HIP_TRY(ctx, hipMalloc(&L->d_sync, need * sizeof(int)));
-            L->sync_cap = need;
+        const size_t lds_bytes = ((size_t)2 * (TILE_H + 4 * kmax) * TILE_NO + TILE_NO + 2 + 25) * sizeof(uint64_t);
+        static bool rattr[kNumVariants] = {};
+        static int per_cu_of[kNumVariants] = {};
+        if (!rattr[vi]) {
+            TSU_HIP_TRY(ctx, hipFuncSetAttribute((const void*)tv.resident, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            int per_cu = 0;
+            TSU_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)tv.resident, tv.threads, lds_bytes));
+            per_cu_of[vi] = per_cu;
+            rattr[vi] = true;
         }
-        if (!L->h_err) {
-            TSU_HIP_TRY(ctx, hipHostMalloc(&L->h_err, sizeof(int), hipHostMallocMapped));
-            *L->h_err = 0;
+        if ((long long)ntiles <= (long long)per_cu_of[vi] * ctx->cus) {
+            const size_t xstride = (size_t)4 * (2 * kmax * TILE_WO) + (size_t)4 * TILE_H;
+            const size_t xneed = (size_t)2 * ntiles * xstride;
+            if (L->xbuf_cap < xneed) {
+                if (L->d_xbuf) (void)hipFree(L->d_xbuf);
+                L->d_xbuf = nullptr;
+                L->xbuf_cap = 0;
+                TSU_HIP_TRY(ctx, hipMalloc(&L->d_xbuf, xneed * sizeof(uint64_t)));
+                L->xbuf_cap = xneed;
+            }
+            if (L->sync_cap < (size_t)ntiles) {
+                if (L->d_sync) (void)hipFree(L->d_sync);
+                L->d_sync = nullptr;
+                L->sync_cap = 0;
+                TSU_HIP_TRY(ctx, hipMalloc(&L->d_sync, (size_t)ntiles * sizeof(int)));
+                L->sync_cap = (size_t)ntiles;
+            }
+            if (!L->h_err) {
+                TSU_HIP_TRY(ctx, hipHostMalloc(&L->h_err, sizeof(int), hipHostMallocMapped));
+                *L->h_err = 0;
+            }
+            int* d_err = nullptr;
+            TSU_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&d_err, L->h_err, 0));
+            ResidentLaunch P;
+            p.k = kmax;
+            p.sweep0 = sweep0;
+            p.ty_first = 0;
+            p.ty_stride = 1;
+            p.src = L->alloc[L->cur] + (size_t)L->ghost * L->pitch;
+            p.dst = L->alloc[L->cur ^ 1] + (size_t)L->ghost * L->pitch;
+            P.t = p;
+            P.r.xbuf = L->d_xbuf;
+            P.r.done = L->d_sync;
+            P.r.err = d_err;
+            P.r.n_gen = (n_sweeps + kmax - 1) / kmax;
+            P.r.k_last = n_sweeps - (P.r.n_gen - 1) * kmax;
+            P.r.tiles_y = tiles_y;
+            P.r.dbg = nullptr;
+            const char* vb = getenv("TSU_K1_VERBOSE");
+            long long* d_dbg = nullptr;
+            if (vb && atoi(vb) >= 2) {
+                TSU_HIP_TRY(ctx, hipMalloc(&d_dbg, 4 * sizeof(long long)));
+                P.r.dbg = d_dbg;
+            }
+            if (getenv("TSU_K1_VERBOSE"))
+                fprintf(stderr, "[tsu] k1_resident variant %d: %d tiles (%d per CU fit), %d generations of %d sweeps, %zu KB of strips\n", vi,
+                        ntiles, per_cu_of[vi], P.r.n_gen, kmax, xneed * 8 / 1024);
+            TSU_HIP_TRY(ctx, hipMemsetAsync(L->d_sync, 0, (size_t)ntiles * sizeof(int), ctx->stream));
+            hipLaunchKernelGGL(tv.resident, dim3((unsigned)ntiles), dim3((unsigned)tv.threads), lds_bytes, ctx->stream, P);
+            L->launches += 1;
+            L->cur ^= 1;
+            TSU_HIP_TRY(ctx, hipGetLastError());
+            if (d_dbg) {
+                long long h[4];
+                (void)hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost);
+                (void)hipFree(d_dbg);
+                fprintf(stderr, "[tsu]   tile 0, us per generation: sweeps %.1f, publish %.1f, wait %.1f, fetch %.1f\n", h[0] / 100.0 / P.r.n_gen,
+                        h[1] / 100.0 / P.r.n_gen, h[2] / 100.0 / P.r.n_gen, h[3] / 100.0 / P.r.n_gen);
+            }
+            return TSU_OK;
         }
-        int* d_err = nullptr;
-        TSU_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&d_err, L->h_err, 0));
-        PersistParams P;
-        p.k = kmax;
-        p.sweep0 = sweep0;
-        p.ty_first = 0;
-        p.ty_stride = 1;
-        P.t = p;
-        P.buf[0] = L->alloc[0] + (size_t)L->ghost * L->pitch;
-        P.buf[1] = L->alloc[1] + (size_t)L->ghost * L->pitch;
-        P.first = L->cur;
-        P.n_gen = (n_sweeps + kmax - 1) / kmax;
-        P.k_last = n_sweeps - (P.n_gen - 1) * kmax;
-        P.tiles_y = tiles_y;
-        P.ticket = L->d_sync;
-        P.done = L->d_sync + 1;
-        P.err = d_err;
-        const int TRmax = TILE_H + 4 * kmax;
-        const size_t lds_bytes = ((size_t)2 * TRmax * TILE_NO + TILE_NO + 2 + 25) * sizeof(uint64_t);
-        static bool pattr[kNumVariants] = {};
-        static int resident[kNumVariants] = {};
-        if (!pattr[vi]) {
-            TSU_HIP_TRY(ctx, hipFuncSetAttribute((const void*)tv.persist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            pattr[vi] = true;
-        }
-        int per_cu = 0;
-        TSU_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)tv.persist, tv.threads, lds_bytes));
-        if (per_cu < 1) per_cu = 1;
-        if (getenv("TSU_K1_VERBOSE") && resident[vi] != per_cu)
-            fprintf(stderr, "[tsu] k1_persist variant %d: %d workgroups/CU, %zu B LDS, %d tiles x %d generations\n", vi, per_cu, lds_bytes, ntiles, P.n_gen);
-        resident[vi] = per_cu;
-        long long grid = (long long)per_cu * ctx->cus;
-        const long long items = (long long)ntiles * P.n_gen;
-        if (grid > items) grid = items;
-        TSU_HIP_TRY(ctx, hipMemsetAsync(L->d_sync, 0, need * sizeof(int), ctx->stream));
-        hipLaunchKernelGGL(tv.persist, dim3((unsigned)grid), dim3((unsigned)tv.threads), lds_bytes, ctx->stream, P);
-        L->cur = (L->cur + P.n_gen) & 1;
-        TSU_HIP_TRY(ctx, hipGetLastError());
-        return TSU_OK;
     }
     for (int done = 0; done < n_sweeps;) {
         int k = n_sweeps - done < kmax ? n_sweeps - done : kmax;
@@ -737,8 +810,10 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
             p.ty_stride = tiles_y - 1;
             n_ty = 2;
         }
-        if (n_ty > 0)
+        if (n_ty > 0) {
             hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_x * n_ty)), dim3((unsigned)tv.threads), lds_bytes, ctx->stream, p);
+            L->launches += 1;
+        }
         if (part != TSU_PART_INTERIOR) L->cur ^= 1;  // INTERIOR does not publish; BOUNDARY (or ALL) does
         done += k;
     }

@@ -71,6 +71,7 @@ SIGNATURES = {
     "tsu_ising2d_row_ptr": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "tsu_ising2d_set_timing": (C.c_int, [_vp, C.c_int]),
     "tsu_ising2d_last_sweep_ms": (C.c_int, [_vp, _f32p]),
+    "tsu_ising2d_launch_count": (C.c_int, [_vp, _u64p]),
     "tsu_dense_create": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _f64p, C.POINTER(_vp)]),
     "tsu_dense_destroy": (C.c_int, [_vp]),
     "tsu_dense_set_state": (C.c_int, [_vp, _i8p]),
@@ -274,6 +275,11 @@ class Lattice:
 
     def set_timing(self, enable=True):
         self.ctx.check(self.lib.tsu_ising2d_set_timing(self.h, int(bool(enable))))
+
+    def launch_count(self):
+        n = C.c_uint64(0)
+        self.ctx.check(self.lib.tsu_ising2d_launch_count(self.h, C.byref(n)))
+        return n.value
 
     def last_sweep_ms(self):
         ms = C.c_float(0)
