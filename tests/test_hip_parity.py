@@ -112,12 +112,13 @@ def test_ising2d_tiled_ties_and_clamps(hip):
 
 @pytest.mark.parametrize("nslab,ghost,k,spl", [(2, 8, 4, 0), (3, 16, 8, 0), (2, 2, 1, 0), (2, 32, 16, 4), (2, 40, 19, 8),
                                                 (3, 24, 12, 5)])
-@pytest.mark.parametrize("periodic", [True, False])
-def test_ising2d_tiled_slabs(hip, nslab, ghost, k, spl, periodic):
+@pytest.mark.parametrize("periodic,cols", [(True, 576), (False, 576), (True, 1024)])
+def test_ising2d_tiled_slabs(hip, nslab, ghost, k, spl, periodic, cols):
     """Row slabs driven through the tiled kernel (ghost rows as the vertical halo) == whole lattice; with
     k > sweeps-per-launch a slab sweeps several launches per ghost refresh, extending into its ghost rows.
-    Open lattices: the outer slabs' ghost rows lie beyond the lattice and count as empty."""
-    per, cols, seed = 128, 576, 31
+    Open lattices: the outer slabs' ghost rows lie beyond the lattice and count as empty.  1024 columns = whole tiles:
+    periodic slabs then keep their tiles in LDS for the whole refresh period (tile-resident generations)."""
+    per, seed = 128, 31
     rows = per * nslab
     table = ora.ising2d_thresholds(1.0, 0.1, 2.269185, 0)
     full = ora.ising2d_randomize(rows, cols, seed)

@@ -269,6 +269,8 @@ struct ResidentParams {
     int* done;       // [tiles] generations published
     int* err;        // host-mapped: set if a bounded wait expired (results invalid)
     int n_gen, k_last, tiles_y;
+    int wrap_y;      // tile rows wrap (whole periodic lattice); 0 for a slab: its outer tile rows have no neighbour there and
+                     // live on the slab's deep ghost rows (the region that is still exact shrinks, as between exchanges)
     long long* dbg;  // TSU_K1_VERBOSE=2: wall_clock64 ticks of tile 0 spent in [sweeps, publish, wait, fetch]
 };
 
@@ -435,12 +437,14 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
         RES_MARK(1);
         const int txl = tx == 0 ? tiles_x - 1 : tx - 1, txr = tx == tiles_x - 1 ? 0 : tx + 1;
         const int tyu = ty == 0 ? tiles_y - 1 : ty - 1, tyd = ty == tiles_y - 1 ? 0 : ty + 1;
+        const bool has_u = R->wrap_y || ty > 0, has_d = R->wrap_y || ty < tiles_y - 1;
         if (tid < 8) {  // the eight neighbours (periodic in tiles), one lane each
             const int nx = (tid == 0 || tid == 3 || tid == 5) ? txl : ((tid == 2 || tid == 4 || tid == 7) ? txr : tx);
             const int ny = tid < 3 ? tyu : (tid < 5 ? ty : tyd);
             const int* flag = R->done + ny * tiles_x + nx;
+            const bool exists = tid < 3 ? has_u : (tid < 5 ? true : has_d);
             int spins = 0;
-            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen + 1) {
+            while (exists && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen + 1) {
                 __builtin_amdgcn_s_sleep(2);
                 // the error flag lives in host memory (a PCIe round trip): look at it rarely
                 if (++spins > (1 << 23) || ((spins & 0xFFF) == 0 && __hip_atomic_load(R->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))) {
@@ -469,9 +473,8 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
             const int e = pl * n_tb + r * WO;
             const uint64_t* pu = o == 0 ? X_ul + 2 * n_tb + e + WO - 1 : (o == NO - 1 ? X_ur + 2 * n_tb + e : X_u + 2 * n_tb + e + o - 1);
             const uint64_t* pd = o == 0 ? X_dl + e + WO - 1 : (o == NO - 1 ? X_dr + e : X_d + e + o - 1);
-            const uint64_t up = xld(pu), dn = xld(pd);
-            P[r * NO + o] = up;
-            P[(2 * k + H + r) * NO + o] = dn;
+            if (has_u) P[r * NO + o] = xld(pu);
+            if (has_d) P[(2 * k + H + r) * NO + o] = xld(pd);
         }
         // halo octets of the interior rows: octet 0 from the left neighbour's RIGHT strip, octet NO-1 from the right one's LEFT
         for (int i = tid; i < 2 * n_lr; i += THREADS) {
@@ -698,22 +701,41 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
         use_resident = e ? atoi(e) : 1;
     }
     const int ntiles = p.tiles_x * tiles_y;
-    if (use_resident && tv.resident && L->periodic && L->wrap_rows && part == TSU_PART_ALL && n_sweeps > kmax && !p.debug &&
-        L->rows % TILE_H == 0 && p.nchunks % TILE_WO == 0) {
+    // whole periodic lattice: tiles of TILE_H rows; periodic slab: its tiles stretched over the ghost rows that the call's
+    // later generations need (uniform even height th, th * tiles_y = rows + 2 ext, 2 (n_sweeps - k) <= ext <= ghost)
+    int res_th = TILE_H, res_ext = 0;
+    bool res_ok = use_resident && tv.resident && L->periodic && part == TSU_PART_ALL && n_sweeps > kmax && !p.debug &&
+                  p.nchunks % TILE_WO == 0;
+    if (res_ok && L->wrap_rows) res_ok = L->rows % TILE_H == 0;
+    else if (res_ok) {
+        const int need = L->rows + 4 * (n_sweeps - kmax);
+        res_th = (need + tiles_y - 1) / tiles_y;
+        res_th += res_th & 1;
+        if (res_th < TILE_H) res_th = TILE_H;
+        const int extra = res_th * tiles_y - L->rows;
+        res_ext = extra / 2;
+        const size_t lds_share = (tv.threads >= 1024 ? 160u : 80u) * 1024u;
+        const size_t lds_need = ((size_t)2 * (res_th + 4 * kmax) * TILE_NO + TILE_NO + 2 + 25) * sizeof(uint64_t);
+        res_ok = (extra % 2 == 0) && res_ext <= L->ghost && lds_need <= lds_share;
+    }
+    if (res_ok) {
         // ---- tile-resident generations: every tile has its own workgroup on the chip for the whole call
         const int vi = (int)(&tv - kVariants);
-        const size_t lds_bytes = ((size_t)2 * (TILE_H + 4 * kmax) * TILE_NO + TILE_NO + 2 + 25) * sizeof(uint64_t);
+        const size_t lds_bytes = ((size_t)2 * (res_th + 4 * kmax) * TILE_NO + TILE_NO + 2 + 25) * sizeof(uint64_t);
         static bool rattr[kNumVariants] = {};
         static int per_cu_of[kNumVariants] = {};
         if (!rattr[vi]) {
             TSU_HIP_TRY(ctx, hipFuncSetAttribute((const void*)tv.resident, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             int per_cu = 0;
-            TSU_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)tv.resident, tv.threads, lds_bytes));
+            // (occupancy for the standard tile height; a stretched slab tile was checked against the variant's LDS share)
+            TSU_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                                 &per_cu, (const void*)tv.resident, tv.threads,
+                                 ((size_t)2 * (TILE_H + 4 * KMAX) * TILE_NO + TILE_NO + 2 + 25) * sizeof(uint64_t)));
             per_cu_of[vi] = per_cu;
             rattr[vi] = true;
         }
         if ((long long)ntiles <= (long long)per_cu_of[vi] * ctx->cus) {
-            const size_t xstride = (size_t)4 * (2 * kmax * TILE_WO) + (size_t)4 * TILE_H;
+            const size_t xstride = (size_t)4 * (2 * kmax * TILE_WO) + (size_t)4 * res_th;
             const size_t xneed = (size_t)2 * ntiles * xstride;
             if (L->xbuf_cap < xneed) {
                 if (L->d_xbuf) (void)hipFree(L->d_xbuf);
@@ -742,7 +764,11 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
             p.ty_stride = 1;
             p.src = L->alloc[L->cur] + (size_t)L->ghost * L->pitch;
             p.dst = L->alloc[L->cur ^ 1] + (size_t)L->ghost * L->pitch;
+            p.tile_h = res_th;
+            p.r_begin = -res_ext;
+            p.r_end = L->rows + res_ext;
             P.t = p;
+            P.r.wrap_y = L->wrap_rows ? 1 : 0;
             P.r.xbuf = L->d_xbuf;
             P.r.done = L->d_sync;
             P.r.err = d_err;

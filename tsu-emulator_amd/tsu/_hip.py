@@ -180,9 +180,9 @@ class Context:
                                               _ptr(out, _u32p)))
         return out
 
-    def __del__(self):
+    def __del__(self, _finalizing=sys.is_finalizing):
         try:
-            if getattr(self, "h", None) and not sys.is_finalizing():
+            if getattr(self, "h", None) and not _finalizing():
                 self.lib.tsu_shutdown(self.h)
                 self.h = None
         except Exception:
@@ -218,8 +218,8 @@ class Lattice:
             self.lib.tsu_ising2d_destroy(self.h)
             self.h = None
 
-    def __del__(self):
-        if not sys.is_finalizing():  # at interpreter exit the process teardown frees the device memory
+    def __del__(self, _finalizing=sys.is_finalizing):
+        if not _finalizing():  # at interpreter exit the process teardown frees the device memory
             self.close()
 
     def set_spins(self, spins, row_first=0):
@@ -336,8 +336,8 @@ class DenseSystem:
             self.lib.tsu_dense_destroy(self.h)
             self.h = None
 
-    def __del__(self):
-        if not sys.is_finalizing():  # at interpreter exit the process teardown frees the device memory
+    def __del__(self, _finalizing=sys.is_finalizing):
+        if not _finalizing():  # at interpreter exit the process teardown frees the device memory
             self.close()
 
     def set_state(self, bits):
@@ -401,8 +401,8 @@ class LangevinChains:
             self.lib.tsu_langevin_destroy(self.h)
             self.h = None
 
-    def __del__(self):
-        if not sys.is_finalizing():  # at interpreter exit the process teardown frees the device memory
+    def __del__(self, _finalizing=sys.is_finalizing):
+        if not _finalizing():  # at interpreter exit the process teardown frees the device memory
             self.close()
 
     def set_state(self, x):
