@@ -296,9 +296,9 @@ def main():
                        "avg_launch_us": avg_launch_ms * 1e3, "algorithmic_bytes_per_launch": alg_bytes_per_launch},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "note": "achieved = algorithmic 2 B/spin-update x L^2 x k per launch / avg launch time (HIP events "
-                                 "on the launch stream over the timed region); the kernel keeps the tile in LDS for k "
-                                 "sweeps, so real HBM traffic is ~2/k B per update and the kernel is VALU (Philox) bound"},
+                         "note": "achieved = algorithmic 2 B/spin-update x sites x sweeps per launch / avg launch time (HIP events "
+                                 "on the launch stream over the timed region); tiles live in LDS for many sweeps, so real "
+                                 "HBM traffic is a small fraction of that and the kernel is VALU (Philox) bound"},
             "observables": {"M": s / (float(rows_local) * L * world), "E_per_site": -b / (float(rows_local) * L * world),
                             "note": "physical mode, random start; u(T_c) = -sqrt(2) = -1.4142 is approached slowly (critical slowing down)"},
         }

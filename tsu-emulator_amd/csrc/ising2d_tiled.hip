@@ -568,7 +568,7 @@ const TileVariant kVariants[] = {
     {128, 32, 512, k1_tiled2<128, 32, 512, 6>, nullptr}, // 19
     {128, 32, 768, k1_tiled2<128, 32, 768, 6>}, // 20: 12 waves per workgroup, 2 workgroups per CU = 6 waves/SIMD
     {128, 32, 640, k1_tiled2<128, 32, 640, 5>}, // 21
-    {256, 32, 1024, k1_tiled2<256, 32, 1024, 4>, nullptr, k1_tiled2<256, 32, 1024, 4, true>}, // 22: one 148 KB workgroup per CU
+    {256, 32, 1024, k1_tiled2<256, 32, 1024, 4>, k1_resident<256, 32, 1024, 4>, k1_tiled2<256, 32, 1024, 4, true>}, // 22: one 148 KB workgroup per CU
     {112, 32, 512, k1_tiled2<112, 32, 512>},      // 23
     {96, 32, 512, k1_tiled2<96, 32, 512, 6>},     // 24
     {160, 32, 512, k1_tiled2<160, 32, 512>},      // 25
