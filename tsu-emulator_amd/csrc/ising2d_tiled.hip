@@ -757,45 +757,52 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
             }
             int* d_err = nullptr;
             TSU_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&d_err, L->h_err, 0));
-            ResidentLaunch P;
-            p.k = kmax;
-            p.sweep0 = sweep0;
-            p.ty_first = 0;
-            p.ty_stride = 1;
-            p.src = L->alloc[L->cur] + (size_t)L->ghost * L->pitch;
-            p.dst = L->alloc[L->cur ^ 1] + (size_t)L->ghost * L->pitch;
-            p.tile_h = res_th;
-            p.r_begin = -res_ext;
-            p.r_end = L->rows + res_ext;
-            P.t = p;
-            P.r.wrap_y = L->wrap_rows ? 1 : 0;
-            P.r.xbuf = L->d_xbuf;
-            P.r.done = L->d_sync;
-            P.r.err = d_err;
-            P.r.n_gen = (n_sweeps + kmax - 1) / kmax;
-            P.r.k_last = n_sweeps - (P.r.n_gen - 1) * kmax;
-            P.r.tiles_y = tiles_y;
-            P.r.dbg = nullptr;
             const char* vb = getenv("TSU_K1_VERBOSE");
-            long long* d_dbg = nullptr;
-            if (vb && atoi(vb) >= 2) {
-                TSU_HIP_TRY(ctx, hipMalloc(&d_dbg, 4 * sizeof(long long)));
-                P.r.dbg = d_dbg;
-            }
-            if (getenv("TSU_K1_VERBOSE"))
-                fprintf(stderr, "[tsu] k1_resident variant %d: %d tiles (%d per CU fit), %d generations of %d sweeps, %zu KB of strips\n", vi,
-                        ntiles, per_cu_of[vi], P.r.n_gen, kmax, xneed * 8 / 1024);
-            TSU_HIP_TRY(ctx, hipMemsetAsync(L->d_sync, 0, (size_t)ntiles * sizeof(int), ctx->stream));
-            hipLaunchKernelGGL(tv.resident, dim3((unsigned)ntiles), dim3((unsigned)tv.threads), lds_bytes, ctx->stream, P);
-            L->launches += 1;
-            L->cur ^= 1;
-            TSU_HIP_TRY(ctx, hipGetLastError());
-            if (d_dbg) {
-                long long h[4];
-                (void)hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost);
-                (void)hipFree(d_dbg);
-                fprintf(stderr, "[tsu]   tile 0, us per generation: sweeps %.1f, publish %.1f, wait %.1f, fetch %.1f\n", h[0] / 100.0 / P.r.n_gen,
-                        h[1] / 100.0 / P.r.n_gen, h[2] / 100.0 / P.r.n_gen, h[3] / 100.0 / P.r.n_gen);
+            // one launch per 1024 generations at most (a whole lattice may be asked for millions of sweeps; a slab's call
+            // is one refresh period anyway)
+            const int chunk_max = L->wrap_rows ? 1024 * kmax : n_sweeps;
+            for (int done = 0; done < n_sweeps;) {
+                const int chunk = n_sweeps - done < chunk_max ? n_sweeps - done : chunk_max;
+                ResidentLaunch P;
+                p.k = kmax;
+                p.sweep0 = sweep0 + (uint32_t)done;
+                p.ty_first = 0;
+                p.ty_stride = 1;
+                p.src = L->alloc[L->cur] + (size_t)L->ghost * L->pitch;
+                p.dst = L->alloc[L->cur ^ 1] + (size_t)L->ghost * L->pitch;
+                p.tile_h = res_th;
+                p.r_begin = -res_ext;
+                p.r_end = L->rows + res_ext;
+                P.t = p;
+                P.r.wrap_y = L->wrap_rows ? 1 : 0;
+                P.r.xbuf = L->d_xbuf;
+                P.r.done = L->d_sync;
+                P.r.err = d_err;
+                P.r.n_gen = (chunk + kmax - 1) / kmax;
+                P.r.k_last = chunk - (P.r.n_gen - 1) * kmax;
+                P.r.tiles_y = tiles_y;
+                P.r.dbg = nullptr;
+                long long* d_dbg = nullptr;
+                if (vb && atoi(vb) >= 2) {
+                    TSU_HIP_TRY(ctx, hipMalloc(&d_dbg, 4 * sizeof(long long)));
+                    P.r.dbg = d_dbg;
+                }
+                if (vb)
+                    fprintf(stderr, "[tsu] k1_resident variant %d: %d tiles (%d per CU fit), %d generations of %d sweeps, %zu KB of strips\n",
+                            vi, ntiles, per_cu_of[vi], P.r.n_gen, kmax, xneed * 8 / 1024);
+                TSU_HIP_TRY(ctx, hipMemsetAsync(L->d_sync, 0, (size_t)ntiles * sizeof(int), ctx->stream));
+                hipLaunchKernelGGL(tv.resident, dim3((unsigned)ntiles), dim3((unsigned)tv.threads), lds_bytes, ctx->stream, P);
+                L->launches += 1;
+                L->cur ^= 1;
+                TSU_HIP_TRY(ctx, hipGetLastError());
+                if (d_dbg) {
+                    long long h[4];
+                    (void)hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost);
+                    (void)hipFree(d_dbg);
+                    fprintf(stderr, "[tsu]   tile 0, us per generation: sweeps %.1f, publish %.1f, wait %.1f, fetch %.1f\n",
+                            h[0] / 100.0 / P.r.n_gen, h[1] / 100.0 / P.r.n_gen, h[2] / 100.0 / P.r.n_gen, h[3] / 100.0 / P.r.n_gen);
+                }
+                done += chunk;
             }
             return TSU_OK;
         }
