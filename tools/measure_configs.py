@@ -19,7 +19,7 @@ def say(s):
 
 
 say(f"device: {ctx.device_info()}")
-say("-- C2 checkerboard sweep, periodic, physical mode, T_c, upd/s (best of 3 x 40 sweeps)")
+say("-- C2 checkerboard sweep, periodic, physical mode, T_c, upd/s (best of 3 x 400 sweeps after 400 warm-up sweeps)")
 for L, k in ((4096, 8), (8192, 5), (16384, 5)):
     for start in ("random", "cold(+1)", "hot->cold T=1.5"):
         lat = _hip.Lattice(L, L, True, ctx=ctx)
@@ -29,7 +29,7 @@ for L, k in ((4096, 8), (8192, 5), (16384, 5)):
             lat.randomize(42)
         lat.set_model(1.0, 0.0, 1.5 if "T=1.5" in start else T_C)
         lat.set_kernel(_hip.KERNEL_AUTO, k)
-        n = 40
+        n = 400
         lat.sweep(n, 42, 0); ctx.synchronize()
         best = 1e9
         for r in range(3):
@@ -49,12 +49,12 @@ for S in (8, 16, 32, 64):
     t0 = time.perf_counter(); slab.sweep(n); slab.synchronize(); torch.cuda.synchronize(); t = time.perf_counter() - t0
     say(f"S={S:3d}: {4096 * 4096 * n / t:.3e} upd/s")
     del slab
-slab = SlabLattice(2048, 16384, periodic=True, sweeps_per_exchange=60, seed=1)
-slab.lat.set_kernel(_hip.KERNEL_AUTO, 5)
+slab = SlabLattice(2048, 16384, periodic=True, sweeps_per_exchange=32, seed=1)
+slab.lat.set_kernel(_hip.KERNEL_AUTO, 8)
 slab.randomize(); slab.set_model(1.0, 0.0, T_C)
-slab.sweep(60); slab.synchronize(); torch.cuda.synchronize()
-t0 = time.perf_counter(); slab.sweep(600); slab.synchronize(); torch.cuda.synchronize(); t = time.perf_counter() - t0
-say(f"C4 shape, one rank's slab 2048 x 16384, k=5, S=60: {2048 * 16384 * 600 / t:.3e} upd/s")
+slab.sweep(64); slab.synchronize(); torch.cuda.synchronize()
+t0 = time.perf_counter(); slab.sweep(640); slab.synchronize(); torch.cuda.synchronize(); t = time.perf_counter() - t0
+say(f"C4 shape, one rank's slab 2048 x 16384, k=8, S=32 (bench.py --strong): {2048 * 16384 * 640 / t:.3e} upd/s")
 del slab
 
 say("-- C3 dense Gibbs, spin-glass J = (G + G^T)/2/sqrt(N), T=1, natural order")
