@@ -270,7 +270,9 @@ struct ResidentParams {
     int* err;        // host-mapped: set if a bounded wait expired (results invalid)
     int n_gen, k_last, tiles_y;
     int wrap_y;      // tile rows wrap (whole periodic lattice); 0 for a slab: its outer tile rows have no neighbour there and
-                     // live on the slab's deep ghost rows (the region that is still exact shrinks, as between exchanges)
+                     // live on the slab's deep ghost rows (the region that is still exact shrinks, as between exchanges),
+                     // and for an open lattice: beyond the edge there is nothing, and nothing stays there
+    int wrap_x;      // tile columns wrap (periodic); 0 for an open lattice
     long long* dbg;  // TSU_K1_VERBOSE=2: wall_clock64 ticks of tile 0 spent in [sweeps, publish, wait, fetch]
 };
 
@@ -438,11 +440,13 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
         const int txl = tx == 0 ? tiles_x - 1 : tx - 1, txr = tx == tiles_x - 1 ? 0 : tx + 1;
         const int tyu = ty == 0 ? tiles_y - 1 : ty - 1, tyd = ty == tiles_y - 1 ? 0 : ty + 1;
         const bool has_u = R->wrap_y || ty > 0, has_d = R->wrap_y || ty < tiles_y - 1;
+        const bool has_l = R->wrap_x || tx > 0, has_r = R->wrap_x || tx < tiles_x - 1;
         if (tid < 8) {  // the eight neighbours (periodic in tiles), one lane each
             const int nx = (tid == 0 || tid == 3 || tid == 5) ? txl : ((tid == 2 || tid == 4 || tid == 7) ? txr : tx);
             const int ny = tid < 3 ? tyu : (tid < 5 ? ty : tyd);
             const int* flag = R->done + ny * tiles_x + nx;
-            const bool exists = tid < 3 ? has_u : (tid < 5 ? true : has_d);
+            const bool exists = (tid < 3 ? has_u : (tid < 5 ? true : has_d)) &&
+                                ((tid == 0 || tid == 3 || tid == 5) ? has_l : ((tid == 2 || tid == 4 || tid == 7) ? has_r : true));
             int spins = 0;
             while (exists && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen + 1) {
                 __builtin_amdgcn_s_sleep(2);
@@ -473,16 +477,16 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
             const int e = pl * n_tb + r * WO;
             const uint64_t* pu = o == 0 ? X_ul + 2 * n_tb + e + WO - 1 : (o == NO - 1 ? X_ur + 2 * n_tb + e : X_u + 2 * n_tb + e + o - 1);
             const uint64_t* pd = o == 0 ? X_dl + e + WO - 1 : (o == NO - 1 ? X_dr + e : X_d + e + o - 1);
-            if (has_u) P[r * NO + o] = xld(pu);
-            if (has_d) P[(2 * k + H + r) * NO + o] = xld(pd);
+            const bool col_ok = o == 0 ? has_l : (o == NO - 1 ? has_r : true);
+            if (has_u && col_ok) P[r * NO + o] = xld(pu);
+            if (has_d && col_ok) P[(2 * k + H + r) * NO + o] = xld(pd);
         }
         // halo octets of the interior rows: octet 0 from the left neighbour's RIGHT strip, octet NO-1 from the right one's LEFT
         for (int i = tid; i < 2 * n_lr; i += THREADS) {
             const int pl = i / n_lr, r = i - pl * n_lr;
             uint64_t* P = pl ? plane1 : plane0;
-            const uint64_t vl = xld(X_l + 4 * n_tb + 2 * n_lr + i), vr = xld(X_r + 4 * n_tb + i);
-            P[(2 * k + r) * NO] = vl;
-            P[(2 * k + r) * NO + NO - 1] = vr;
+            if (has_l) P[(2 * k + r) * NO] = xld(X_l + 4 * n_tb + 2 * n_lr + i);
+            if (has_r) P[(2 * k + r) * NO + NO - 1] = xld(X_r + 4 * n_tb + i);
         }
         RES_MARK(3);
     }
@@ -526,11 +530,11 @@ struct ResidentLaunch {
     ResidentParams r;
 };
 
-template <int H, int WO, int THREADS, int MINW = 1>
+template <int H, int WO, int THREADS, int MINW = 1, bool OPEN = false>
 __global__ __launch_bounds__(THREADS, MINW) void k1_resident(ResidentLaunch P) {
     extern __shared__ uint64_t lds[];
     const PhiloxKeys K = make_keys(P.t.k0, P.t.k1);
-    tile_body<H, WO, THREADS, false, true>(P.t, P.t.src, P.t.dst, P.t.k, P.t.sweep0, blockIdx.x % P.t.tiles_x, blockIdx.x / P.t.tiles_x,
+    tile_body<H, WO, THREADS, OPEN, true>(P.t, P.t.src, P.t.dst, P.t.k, P.t.sweep0, blockIdx.x % P.t.tiles_x, blockIdx.x / P.t.tiles_x,
                                           lds, K, &P.r);
 }
 
@@ -543,6 +547,7 @@ struct TileVariant {
     void (*kernel)(TiledParams);
     void (*resident)(ResidentLaunch);  // tile-resident multi-generation form (nullptr: not built for this shape)
     void (*open)(TiledParams);       // open-boundary form (nullptr: not built for this shape)
+    void (*resident_open)(ResidentLaunch);
 };
 // tile shapes compiled in; TSU_TILE_VARIANT (env, development aid) or tsu_ising2d_set_kernel picks one
 const TileVariant kVariants[] = {
@@ -555,7 +560,7 @@ const TileVariant kVariants[] = {
     {64, 32, 512, k1_tiled2<64, 32, 512>, k1_resident<64, 32, 512>, k1_tiled2<64, 32, 512, 1, true>},    // 6
     {64, 32, 256, k1_tiled2<64, 32, 256>},    // 7
     {128, 32, 512, k1_tiled2<128, 32, 512>, k1_resident<128, 32, 512>, k1_tiled2<128, 32, 512, 1, true>},  // 8
-    {128, 32, 1024, k1_tiled2<128, 32, 1024>, k1_resident<128, 32, 1024>, k1_tiled2<128, 32, 1024, 1, true>},// 9
+    {128, 32, 1024, k1_tiled2<128, 32, 1024>, k1_resident<128, 32, 1024>, k1_tiled2<128, 32, 1024, 1, true>, k1_resident<128, 32, 1024, 1, true>},// 9
     {64, 32, 1024, k1_tiled2<64, 32, 1024>},  // 10
     {64, 32, 576, k1_tiled2<64, 32, 576>},    // 11
     {128, 32, 640, k1_tiled2<128, 32, 640>},  // 12
@@ -568,7 +573,7 @@ const TileVariant kVariants[] = {
     {128, 32, 512, k1_tiled2<128, 32, 512, 6>, nullptr}, // 19
     {128, 32, 768, k1_tiled2<128, 32, 768, 6>}, // 20: 12 waves per workgroup, 2 workgroups per CU = 6 waves/SIMD
     {128, 32, 640, k1_tiled2<128, 32, 640, 5>}, // 21
-    {256, 32, 1024, k1_tiled2<256, 32, 1024, 4>, k1_resident<256, 32, 1024, 4>, k1_tiled2<256, 32, 1024, 4, true>}, // 22: one 148 KB workgroup per CU
+    {256, 32, 1024, k1_tiled2<256, 32, 1024, 4>, k1_resident<256, 32, 1024, 4>, k1_tiled2<256, 32, 1024, 4, true>, k1_resident<256, 32, 1024, 4, true>}, // 22: one 148 KB workgroup per CU
     {112, 32, 512, k1_tiled2<112, 32, 512>},      // 23
     {96, 32, 512, k1_tiled2<96, 32, 512, 6>},     // 24
     {160, 32, 512, k1_tiled2<160, 32, 512>},      // 25
@@ -704,9 +709,9 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
     // whole periodic lattice: tiles of TILE_H rows; periodic slab: its tiles stretched over the ghost rows that the call's
     // later generations need (uniform even height th, th * tiles_y = rows + 2 ext, 2 (n_sweeps - k) <= ext <= ghost)
     int res_th = TILE_H, res_ext = 0;
-    bool res_ok = use_resident && tv.resident && L->periodic && part == TSU_PART_ALL && n_sweeps > kmax && !p.debug &&
-                  p.nchunks % TILE_WO == 0;
-    if (res_ok && L->wrap_rows) res_ok = L->rows % TILE_H == 0;
+    void (*const res_kern)(ResidentLaunch) = L->periodic ? tv.resident : tv.resident_open;
+    bool res_ok = use_resident && res_kern && part == TSU_PART_ALL && n_sweeps > kmax && !p.debug && p.nchunks % TILE_WO == 0;
+    if (res_ok && (L->wrap_rows || open_whole)) res_ok = L->rows % TILE_H == 0;
     else if (res_ok) {
         const int need = L->rows + 4 * (n_sweeps - kmax);
         res_th = (need + tiles_y - 1) / tiles_y;
@@ -722,19 +727,21 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
         // ---- tile-resident generations: every tile has its own workgroup on the chip for the whole call
         const int vi = (int)(&tv - kVariants);
         const size_t lds_bytes = ((size_t)2 * (res_th + 4 * kmax) * TILE_NO + TILE_NO + 2 + 25) * sizeof(uint64_t);
-        static bool rattr[kNumVariants] = {};
-        static int per_cu_of[kNumVariants] = {};
-        if (!rattr[vi]) {
-            TSU_HIP_TRY(ctx, hipFuncSetAttribute((const void*)tv.resident, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        static bool rattr_[kNumVariants][2] = {};
+        static int per_cu_[kNumVariants][2] = {};
+        bool& rattr_vi = rattr_[vi][p.open];
+        if (!rattr_vi) {
+            TSU_HIP_TRY(ctx, hipFuncSetAttribute((const void*)res_kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             int per_cu = 0;
             // (occupancy for the standard tile height; a stretched slab tile was checked against the variant's LDS share)
             TSU_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                                 &per_cu, (const void*)tv.resident, tv.threads,
+                                 &per_cu, (const void*)res_kern, tv.threads,
                                  ((size_t)2 * (TILE_H + 4 * KMAX) * TILE_NO + TILE_NO + 2 + 25) * sizeof(uint64_t)));
-            per_cu_of[vi] = per_cu;
-            rattr[vi] = true;
+            per_cu_[vi][p.open] = per_cu;
+            rattr_vi = true;
         }
-        if ((long long)ntiles <= (long long)per_cu_of[vi] * ctx->cus) {
+        const int fit_per_cu = per_cu_[vi][p.open];
+        if ((long long)ntiles <= (long long)fit_per_cu * ctx->cus) {
             const size_t xstride = (size_t)4 * (2 * kmax * TILE_WO) + (size_t)4 * res_th;
             const size_t xneed = (size_t)2 * ntiles * xstride;
             if (L->xbuf_cap < xneed) {
@@ -760,7 +767,7 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
             const char* vb = getenv("TSU_K1_VERBOSE");
             // one launch per 1024 generations at most (a whole lattice may be asked for millions of sweeps; a slab's call
             // is one refresh period anyway)
-            const int chunk_max = L->wrap_rows ? 1024 * kmax : n_sweeps;
+            const int chunk_max = (L->wrap_rows || open_whole) ? 1024 * kmax : n_sweeps;
             for (int done = 0; done < n_sweeps;) {
                 const int chunk = n_sweeps - done < chunk_max ? n_sweeps - done : chunk_max;
                 ResidentLaunch P;
@@ -775,6 +782,7 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
                 p.r_end = L->rows + res_ext;
                 P.t = p;
                 P.r.wrap_y = L->wrap_rows ? 1 : 0;
+                P.r.wrap_x = L->periodic ? 1 : 0;
                 P.r.xbuf = L->d_xbuf;
                 P.r.done = L->d_sync;
                 P.r.err = d_err;
@@ -789,9 +797,9 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
                 }
                 if (vb)
                     fprintf(stderr, "[tsu] k1_resident variant %d: %d tiles (%d per CU fit), %d generations of %d sweeps, %zu KB of strips\n",
-                            vi, ntiles, per_cu_of[vi], P.r.n_gen, kmax, xneed * 8 / 1024);
+                            vi, ntiles, fit_per_cu, P.r.n_gen, kmax, xneed * 8 / 1024);
                 TSU_HIP_TRY(ctx, hipMemsetAsync(L->d_sync, 0, (size_t)ntiles * sizeof(int), ctx->stream));
-                hipLaunchKernelGGL(tv.resident, dim3((unsigned)ntiles), dim3((unsigned)tv.threads), lds_bytes, ctx->stream, P);
+                hipLaunchKernelGGL(res_kern, dim3((unsigned)ntiles), dim3((unsigned)tv.threads), lds_bytes, ctx->stream, P);
                 L->launches += 1;
                 L->cur ^= 1;
                 TSU_HIP_TRY(ctx, hipGetLastError());
