@@ -66,7 +66,8 @@ def test_ising2d_sweep_bit_exact(hip, rows, cols, periodic, kernel):
         lat.close()
 
 
-TILED_LATTICES = [(96, 544), (128, 1024), (130, 560), (200, 2080), (256, 4096)]
+TILED_LATTICES = [(96, 544), (128, 1024), (130, 560), (200, 2080), (256, 4096),
+                  (96, 288), (128, 320), (256, 512), (1024, 1024)]  # narrower lattices: 256-column tiles
 
 
 @pytest.mark.parametrize("periodic", [True, False])

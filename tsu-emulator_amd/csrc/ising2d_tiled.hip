@@ -574,6 +574,11 @@ const TileVariant kVariants[] = {
     {128, 32, 768, k1_tiled2<128, 32, 768, 6>}, // 20: 12 waves per workgroup, 2 workgroups per CU = 6 waves/SIMD
     {128, 32, 640, k1_tiled2<128, 32, 640, 5>}, // 21
     {256, 32, 1024, k1_tiled2<256, 32, 1024, 4>, k1_resident<256, 32, 1024, 4>, k1_tiled2<256, 32, 1024, 4, true>, k1_resident<256, 32, 1024, 4, true>}, // 22: one 148 KB workgroup per CU
+    {128, 16, 1024, k1_tiled2<128, 16, 1024>, k1_resident<128, 16, 1024>},  // 23: narrower tiles for mid-size lattices
+    {64, 16, 512, k1_tiled2<64, 16, 512>, k1_resident<64, 16, 512>},        // 24
+    {64, 32, 1024, k1_tiled2<64, 32, 1024>, k1_resident<64, 32, 1024>},     // 25
+    {64, 16, 1024, k1_tiled2<64, 16, 1024>, k1_resident<64, 16, 1024>, k1_tiled2<64, 16, 1024, 1, true>, k1_resident<64, 16, 1024, 1, true>},  // 26
+    {32, 16, 1024, k1_tiled2<32, 16, 1024>, k1_resident<32, 16, 1024>},     // 27
     {112, 32, 512, k1_tiled2<112, 32, 512>},      // 23
     {96, 32, 512, k1_tiled2<96, 32, 512, 6>},     // 24
     {160, 32, 512, k1_tiled2<160, 32, 512>},      // 25
@@ -602,19 +607,49 @@ int pick_variant(const tsu_ising2d* L) {
         else if (n128 <= 2 * cus && n256 <= cus && 10 * n256 >= 7 * cus) v = 22;
         else v = 8;
         if (L->rows < 256) v = 6;
+        // Lattices that fit the chip's LDS whole (every tile its own workgroup, tile-resident generations): the tile
+        // shape that finishes a generation of 8 sweeps soonest.  Model fitted to measurements (4096^2, 2048^2, 1024^2,
+        // 4096 x 8192; profiles/r01_k1_experiments.txt): a half-sweep costs 0.25 us + 0.225 us per wave-iteration of the
+        // busiest SIMD, the strip exchange 4.3 us per generation.
+        static const int cand[] = {22, 9, 23, 25, 26, 27};
+        double best = 1e30;
+        const bool whole = L->ghost == 0 && L->total_rows == L->rows;
+        for (int ci = 0; whole && ci < (int)(sizeof(cand) / sizeof(cand[0])); ++ci) {
+            const TileVariant& c = kVariants[cand[ci]];
+            if (!(L->periodic ? c.resident : c.resident_open)) continue;
+            if (L->rows % c.H || (L->cols / 16) % c.WO || L->cols / 16 < c.WO + 2 || L->total_rows < c.H + 4 * KMAX) continue;
+            const long long nt = (long long)(L->rows / c.H) * ((L->cols / 16) / c.WO);
+            if (nt > cus) continue;
+            const int pairs = (c.H + 4 * 8 - 2) / 2, waves = (pairs * (c.WO + 2) + 63) / 64;
+            const double t_gen = 16.0 * (0.25 + 0.225 * ((waves + 3) / 4)) + 4.3;
+            if (t_gen < best) {
+                best = t_gen;
+                v = cand[ci];
+            }
+        }
     }
-    // a variant must fit the lattice (tile not wider than the lattice; single wrap of the global row index)
-    if (L->cols / 16 < kVariants[v].WO + 2 || L->total_rows < kVariants[v].H + 4 * KMAX) v = 6;
-    if (L->cols / 16 < kVariants[v].WO + 2 || L->total_rows < kVariants[v].H + 4 * KMAX) v = 0;
+    // a variant must fit the lattice (tile not wider than the lattice; single wrap of the global row index) and, for an
+    // open lattice, have the OPEN form built; -1 = none does (generic kernel)
+    auto fits = [&](int vv) {
+        return L->cols / 16 >= kVariants[vv].WO + 2 && L->total_rows >= kVariants[vv].H + 4 * KMAX && (L->periodic || kVariants[vv].open);
+    };
+    if (!fits(v)) {
+        static const int fallback[] = {6, 26, 27};
+        v = -1;
+        for (int f : fallback)
+            if (fits(f)) {
+                v = f;
+                break;
+            }
+    }
     return v;
 }
 }  // namespace
 
 int tsu_ising2d_tiled_supported(const tsu_ising2d* L) {
     if (L->cols % 16 != 0) return 0;                          // octets must align with 16-byte chunks
-    if (L->cols / 16 < kVariants[0].WO + 2) return 0;         // tile wider than the lattice: generic kernel
+    if (pick_variant(L) < 0) return 0;                        // no tile shape fits (too narrow / too few rows): generic kernel
     const bool open_whole = !L->periodic && L->ghost == 0 && L->total_rows == L->rows;  // beyond its edges: nothing
-    if (!L->periodic && !kVariants[pick_variant(L)].open) return 0;  // open edges need the OPEN form of the kernel
     if (!L->wrap_rows && !open_whole && L->ghost < 2) return 0;
     if (L->total_rows < kVariants[0].H + 4 * KMAX) return 0;  // single wrap of the global row index
     return 1;
