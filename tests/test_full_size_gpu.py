@@ -41,8 +41,27 @@ def test_config2_lattice_4096_matches_oracle_and_generic_kernel(hip):
     gen.set_thresholds(table)
     gen.sweep(n, seed, sweep0=0)
     np.testing.assert_array_equal(gen.get_spins(), got)
+    # a longer call: nine tile-resident generations (strips exchanged between neighbouring tiles) == 144 generic launches
+    lat.sweep(72, seed, sweep0=n)
+    gen.sweep(72, seed, sweep0=n)
+    assert zlib.crc32(lat.get_spins().tobytes()) == zlib.crc32(gen.get_spins().tobytes())
+    assert lat.observables() == gen.observables()
     lat.close()
     gen.close()
+
+
+def test_lattice_2pow25_sites_resident_256_row_tiles(hip):
+    """4096 x 8192 (the largest lattice that stays resident in LDS: 256 tiles of 256 x 512): 40 sweeps == generic kernel."""
+    sums = []
+    for kern in (hip.KERNEL_AUTO, hip.KERNEL_GENERIC):
+        lat = hip.Lattice(4096, 8192, True)
+        lat.set_kernel(kern)
+        lat.randomize(9)
+        lat.set_model(1.0, 0.02, T_C)
+        lat.sweep(40, 9, sweep0=1)
+        sums.append((zlib.crc32(lat.get_spins().tobytes()), lat.observables()))
+        lat.close()
+    assert sums[0] == sums[1]
 
 
 def test_config2_lattice_8192_kernels_agree(hip):
