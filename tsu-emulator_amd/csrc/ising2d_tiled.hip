@@ -8,7 +8,9 @@
 //     2k halo rows, one halo octet = 16 columns >= 2k each side), and
 //   * writes the H x 16 WO interior to the OTHER lattice buffer (neighbouring tiles read this tile's pre-launch
 //     halo, so the launch is out of place; the host ping-pongs).
-// HBM traffic is 2/k bytes per spin update instead of 2; the kernel is VALU bound (Philox), so per octet:
+// When every tile of the lattice has its own workgroup on the chip (up to 2^25 sites), k1_resident keeps the tiles in
+// LDS for a whole call and only exchanges boundary strips between generations of k sweeps (see ResidentParams).
+// HBM traffic is 2/k bytes per spin update instead of 2 (far less when resident); the kernel is VALU bound (Philox), so per octet:
 //   one Philox4x32-10 block -> 8 x 16 random bits; neighbour sums with packed byte adds; 16-bit thresholds
 //   picked per site with v_perm_b32 byte look-ups; v_pk_sub_i16 (saturating) compares two sites per
 //   instruction; only an exact tie of the top 16 bits (2^-16 per site) evaluates the low half.
