@@ -1,0 +1,32 @@
+"""Randomized check of the dense sweep paths against the oracle (development aid)."""
+import os, sys, random
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tsu-emulator_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+from tsu import _hip
+from oracle import oracle as ora
+random.seed(int(os.environ.get("FUZZ_SEED", "5")))
+for case in range(int(os.environ.get("FUZZ_CASES", "30"))):
+    n = random.choice([1, 7, 63, 64, 65, 127, 128, 129, 500, 1023, 2050, 4096, 4097, 5555])
+    f32 = random.random() < 0.5
+    sym = random.random() < 0.7
+    T = random.choice([0.1, 0.5, 1.0, 3.0])
+    sweeps = random.choice([1, 2, 5, 13])
+    rng = np.random.default_rng(random.getrandbits(30))
+    J = rng.standard_normal((n, n)) / max(1.0, np.sqrt(n)) * random.choice([0.3, 1.0, 3.0])
+    if sym:
+        J = (J + J.T) / 2
+    if f32:
+        J = J.astype(np.float32).astype(np.float64)
+    b = rng.normal(size=n) * 0.3 if random.random() < 0.5 else None
+    st = rng.integers(0, 2, size=n).astype(np.int8)
+    d = _hip.DenseSystem(J, b, _hip.DTYPE_F32 if f32 else _hip.DTYPE_F64)
+    d.set_state(st)
+    seed, s0 = random.getrandbits(40), random.randrange(1000)
+    d.sweep(T, sweeps, seed=seed, sweep0=s0)
+    ok = (d.get_state() == ora.dense_sweep_philox(st, J, b, T, sweeps, seed, sweep0=s0)).all()
+    print(("ok  " if ok else "FAIL"), "n", n, "f32" if f32 else "f64", "sym" if sym else "asym", "T", T, "sweeps", sweeps, flush=True)
+    d.close()
+    if not ok:
+        sys.exit(1)
+print("all dense cases agree")
