@@ -23,6 +23,8 @@ struct tsu_ising2d {
     int* d_sync;         // tile-resident kernel: per-tile generation counters
     uint64_t* d_xbuf;    // tile-resident kernel: exchange strips
     size_t xbuf_cap;
+    void* d_batch;       // tsu_ising2d_sweep_batch: device copy of the per-lattice launch items
+    size_t batch_cap;
     size_t sync_cap;     // ints allocated in d_sync
     int* h_err;          // host-mapped flag the tile-resident kernel sets if a bounded wait expires
 };

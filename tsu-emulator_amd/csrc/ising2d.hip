@@ -446,6 +446,8 @@ int tsu_ising2d_create_slab(tsu_ctx* ctx, int64_t total_rows, int cols, int peri
     L->d_sync = nullptr;
     L->d_xbuf = nullptr;
     L->xbuf_cap = 0;
+    L->d_batch = nullptr;
+    L->batch_cap = 0;
     L->sync_cap = 0;
     L->h_err = nullptr;
     size_t bytes = (size_t)(rows + 2 * ghost) * L->pitch;
@@ -478,6 +480,7 @@ int tsu_ising2d_destroy(tsu_ising2d* L) {
     if (L->d_obs) (void)hipFree(L->d_obs);
     if (L->d_sync) (void)hipFree(L->d_sync);
     if (L->d_xbuf) (void)hipFree(L->d_xbuf);
+    if (L->d_batch) (void)hipFree(L->d_batch);
     if (L->h_err) (void)hipHostFree(L->h_err);
     (void)hipEventDestroy(L->ev0);
     (void)hipEventDestroy(L->ev1);
@@ -757,18 +760,23 @@ int tsu_ising2d_sweep_batch(tsu_ising2d* const* lats, int n_lats, int n_sweeps, 
         it.sweep0 = sweep0s[i];
     }
     const size_t bytes = items.size() * sizeof(K1BatchItem);
-    K1BatchItem* d_items = nullptr;
-    TSU_HIP_TRY(ctx, hipMalloc(&d_items, bytes));
-    hipError_t e = hipMemcpyAsync(d_items, items.data(), bytes, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) {
-        const int nchunks = (lats[0]->cols + 15) >> 4, tasks = lats[0]->rows * nchunks;
-        const unsigned threads = tasks >= 1024 ? 1024u : (unsigned)((tasks + 63) / 64 * 64);
-        k1_small_batch<<<(unsigned)n_lats, threads, (size_t)tasks * 16, ctx->stream>>>(d_items, n_sweeps);
-        e = hipGetLastError();
+    tsu_ising2d* L0 = lats[0];  // the staging buffer for the items lives with the first lattice of the batch
+    if (L0->batch_cap < bytes) {
+        if (L0->d_batch) (void)hipFree(L0->d_batch);
+        L0->d_batch = nullptr;
+        L0->batch_cap = 0;
+        TSU_HIP_TRY(ctx, hipMalloc(&L0->d_batch, bytes));
+        L0->batch_cap = bytes;
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // `items` and d_items live until the launch has read them
-    (void)hipFree(d_items);
-    if (e != hipSuccess) return tsu_fail(ctx, TSU_E_HIP, "ising2d_sweep_batch: %s", hipGetErrorString(e));
+    // stream order keeps a previous batch launch from still reading the buffer; the host array dies with this call, so
+    // the copy is waited for (a few KB); the launch itself stays asynchronous
+    TSU_HIP_TRY(ctx, hipMemcpyAsync(L0->d_batch, items.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+    TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const int nchunks = (lats[0]->cols + 15) >> 4, tasks = lats[0]->rows * nchunks;
+    const unsigned threads = tasks >= 1024 ? 1024u : (unsigned)((tasks + 63) / 64 * 64);
+    k1_small_batch<<<(unsigned)n_lats, threads, (size_t)tasks * 16, ctx->stream>>>((const K1BatchItem*)L0->d_batch, n_sweeps);
+    TSU_HIP_TRY(ctx, hipGetLastError());
+    for (int i = 0; i < n_lats; ++i) lats[i]->launches += 1;
     return TSU_OK;
 }
 
