@@ -179,6 +179,13 @@ int tsu_dense_sample(tsu_dense* d, double T, int n_burnin, int n_sweeps, int n_s
  * natural order: one launch of a single wave for the whole schedule. */
 int tsu_dense_anneal(tsu_dense* d, const double* temperatures, int n_steps, const int64_t* order, uint64_t seed,
                      uint32_t sweep0, uint32_t replica, const double* replay_uniforms, int8_t* states_host);
+/* The replica loop of GibbsSampler.parallel_tempering (tsu/gibbs.py:300-306): replica r does n_sweeps sweeps of its own
+ * state (states_host[r*n .. ], in and out) at temperatures[r] with its own seed / sweep counter / replica id;
+ * replay_uniforms: NULL or n_replicas * n_sweeps * n doubles.  The handle's resident state is not used.  n <= 64: one
+ * launch, one wave per replica; larger systems are swept one replica after the other. */
+int tsu_dense_sweep_replicas(tsu_dense* d, int n_replicas, const double* temperatures, int n_sweeps, int8_t* states_host,
+                             const uint64_t* seeds, const uint32_t* sweep0s, const uint32_t* replicas,
+                             const double* replay_uniforms);
 int tsu_dense_energy(tsu_dense* d, double* energy); /* -1/2 s^T J s - b^T s of the resident state */
 
 /* ------------------------------------------------------------------ Langevin (K3)

@@ -359,6 +359,29 @@ def test_dense_sample_run_matches_oracle(hip, n):
     d.close()
 
 
+@pytest.mark.parametrize("n", [10, 64, 100])
+def test_dense_sweep_replicas_match_oracle(hip, n):
+    """tsu_dense_sweep_replicas (a tempering ladder's replica loop in one call; one wave per replica for n <= 64):
+    each replica == the oracle's chain at its temperature / seed / counter; replayed uniforms likewise."""
+    rng = np.random.default_rng(n)
+    J = rng.normal(size=(n, n)) / np.sqrt(n)
+    J = (J + J.T) / 2
+    b = rng.normal(size=n) * 0.2
+    R, ns = 4, 6
+    Ts = [0.5, 1.0, 2.0, 4.0]
+    st = rng.integers(0, 2, size=(R, n)).astype(np.int8)
+    seeds, s0s, reps = [11, 22, 33, 44], [0, 5, 9, 100], [0, 1, 2, 3]
+    d = hip.DenseSystem(J, b)
+    got = d.sweep_replicas(st, Ts, ns, seeds, s0s, reps)
+    for r in range(R):
+        np.testing.assert_array_equal(got[r], ora.dense_sweep_philox(st[r], J, b, Ts[r], ns, seeds[r], sweep0=s0s[r], replica=reps[r]))
+    u = rng.random(size=(R, ns, n))
+    got = d.sweep_replicas(st, Ts, ns, [0] * R, [0] * R, replay_uniforms=u)
+    for r in range(R):
+        np.testing.assert_array_equal(got[r].astype(np.int64), ora.c_dense_sweep_replay(st[r], J, b, Ts[r], u[r], None))
+    d.close()
+
+
 def test_dense_long_run_stays_on_the_oracle_chain(hip):
     """Soak for the cooperative kernel's barrier / agent-scope data path: 200 sweeps of a 5000-site glass (two
     superblocks, ~4000 grid barriers, fields handed on between sweeps) in ONE call stay bit-identical to the oracle."""

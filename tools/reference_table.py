@@ -44,3 +44,12 @@ for rng in ("philox", "numpy"):
         best, e = s.simulated_annealing(-2.0 * W, bias=W.sum(1), n_steps=1000)  # E = -(cut weight)
         ts.append(time.time() - t0)
     print(f"rng={rng:6s} simulated_annealing n=15, 1000 steps: {np.median(ts[1:]) * 1e3:8.2f} ms   (reference publishes 17.6 ms)  cut found {-e:.0f} of {W.sum() / 2:.0f} edges", flush=True)
+
+# parallel tempering, n=10 chain, 4 temperatures, 500 samples (not in the reference's published table; before the replica
+# loop became one device call this took ~3 device round trips per replica per sample)
+for rng in ("philox", "numpy"):
+    np.random.seed(3)
+    s = GibbsSampler(GibbsConfig(temperature=1.0, n_burnin=50, n_sweeps=5), rng=rng)
+    t0 = time.time()
+    samples, info = s.parallel_tempering(chain(10), [0.5, 1.0, 2.0, 4.0], n_samples=500)
+    print(f"rng={rng:6s} parallel_tempering n=10, 4 replicas, 500 samples: {(time.time() - t0) * 1e3:8.1f} ms  swap acceptance {info['swap_acceptance_rate']:.2f}", flush=True)

@@ -37,6 +37,8 @@ struct tsu_dense {
     size_t samples_cap;
     double* temps;      // device copy of an annealing schedule (tsu_dense_anneal)
     size_t temps_cap;
+    void* rep_buf;      // tsu_dense_sweep_replicas: states, replayed uniforms and per-replica parameters
+    size_t rep_cap;
     int co_disabled;    // cooperative launch unavailable or failed once: use the multi-launch path
 };
 

@@ -145,10 +145,10 @@ __global__ __launch_bounds__(256) void k2_block(const TJ* __restrict__ J, const 
 // recorded state after each group) inside one wave.  Lane k owns site k; J sits in LDS as columns; every sweep
 // recomputes the fields from scratch (like the reference's np.dot per site) and resolves the sequential pass by jumping from flip to flip (ballot + ffs) as k2_block does.
 template <typename TJ>
-__global__ __launch_bounds__(64) void k2_small(const TJ* __restrict__ J, const double* __restrict__ bias, int8_t* __restrict__ state,
-                                              const double* __restrict__ uniforms, int8_t* __restrict__ samples, int n, double T,
-                                              const double* __restrict__ temps, int n_burnin, int n_sweeps, int n_samples,
-                                              uint32_t sweep0, uint32_t tag, uint32_t k0, uint32_t k1) {
+static __device__ __forceinline__ void k2_small_body(const TJ* __restrict__ J, const double* __restrict__ bias, int8_t* __restrict__ state,
+                                                     const double* __restrict__ uniforms, int8_t* __restrict__ samples, int n, double T,
+                                                     const double* __restrict__ temps, int n_burnin, int n_sweeps, int n_samples,
+                                                     uint32_t sweep0, uint32_t tag, uint32_t k0, uint32_t k1) {
     __shared__ double col[DB][DB + 1];  // col[i][k] = J[k][i]
     const int lane = threadIdx.x;
     const bool on = lane < n;
@@ -203,6 +203,29 @@ __global__ __launch_bounds__(64) void k2_small(const TJ* __restrict__ J, const d
         }
     }
     if (on) state[lane] = (int8_t)bit;
+}
+
+template <typename TJ>
+__global__ __launch_bounds__(64) void k2_small(const TJ* __restrict__ J, const double* __restrict__ bias, int8_t* __restrict__ state,
+                                              const double* __restrict__ uniforms, int8_t* __restrict__ samples, int n, double T,
+                                              const double* __restrict__ temps, int n_burnin, int n_sweeps, int n_samples,
+                                              uint32_t sweep0, uint32_t tag, uint32_t k0, uint32_t k1) {
+    k2_small_body<TJ>(J, bias, state, uniforms, samples, n, T, temps, n_burnin, n_sweeps, n_samples, sweep0, tag, k0, k1);
+}
+
+// the replicas of a tempering ladder: block r sweeps state r at its own temperature with its own stream
+struct K2Replica {
+    double T;
+    uint32_t sweep0, tag, k0, k1;
+};
+
+template <typename TJ>
+__global__ __launch_bounds__(64) void k2_small_replicas(const TJ* __restrict__ J, const double* __restrict__ bias, int8_t* __restrict__ states,
+                                                       const double* __restrict__ uniforms, const K2Replica* __restrict__ reps, int n,
+                                                       int n_sweeps) {
+    const K2Replica rp = reps[blockIdx.x];
+    k2_small_body<TJ>(J, bias, states + (size_t)blockIdx.x * n, uniforms ? uniforms + (size_t)blockIdx.x * n_sweeps * n : nullptr, nullptr, n,
+                      rp.T, nullptr, n_sweeps, 1, 0, rp.sweep0, rp.tag, rp.k0, rp.k1);
 }
 
 __global__ __launch_bounds__(256) void k2_energy(const double* __restrict__ f, const int8_t* __restrict__ s,
@@ -497,6 +520,7 @@ int tsu_dense_destroy(tsu_dense* d) {
     if (d->backup) (void)hipFree(d->backup);
     if (d->samples) (void)hipFree(d->samples);
     if (d->temps) (void)hipFree(d->temps);
+    if (d->rep_buf) (void)hipFree(d->rep_buf);
     if (d->co_logit) (void)hipFree(d->co_logit);
     if (d->co_corr) (void)hipFree(d->co_corr);
     if (d->co_d0) (void)hipFree(d->co_d0);
@@ -620,6 +644,7 @@ static int dense_run(tsu_dense* d, double T, const double* temps, int n_burnin, 
     if (d->samples_cap < out_bytes) {
         if (d->samples) (void)hipFree(d->samples);
     if (d->temps) (void)hipFree(d->temps);
+    if (d->rep_buf) (void)hipFree(d->rep_buf);
         d->samples = nullptr;
         d->samples_cap = 0;
         TSU_HIP_TRY(ctx, hipMalloc(&d->samples, out_bytes));
@@ -630,6 +655,7 @@ static int dense_run(tsu_dense* d, double T, const double* temps, int n_burnin, 
         if (temps && total > 0) {
             if (d->temps_cap < (size_t)total) {
                 if (d->temps) (void)hipFree(d->temps);
+    if (d->rep_buf) (void)hipFree(d->rep_buf);
                 d->temps = nullptr;
                 d->temps_cap = 0;
                 TSU_HIP_TRY(ctx, hipMalloc(&d->temps, (size_t)total * 8));
@@ -694,6 +720,65 @@ int tsu_dense_anneal(tsu_dense* d, const double* temperatures, int n_steps, cons
     TSU_REQUIRE(d->ctx, n_steps >= 0 && (n_steps == 0 || temperatures), "dense_anneal: need n_steps >= 0 and a temperature per step");
     for (int s = 0; s < n_steps; ++s) TSU_REQUIRE(d->ctx, temperatures[s] > 0.0, "Temperature must be positive");
     return dense_run(d, 1.0, temperatures, 0, 1, n_steps, order, seed, sweep0, replica, replay_uniforms, states_host);
+}
+
+int tsu_dense_sweep_replicas(tsu_dense* d, int n_replicas, const double* temperatures, int n_sweeps, int8_t* states_host,
+                             const uint64_t* seeds, const uint32_t* sweep0s, const uint32_t* replicas, const double* replay_uniforms) {
+    if (!d) return TSU_E_INVALID;
+    tsu_ctx* ctx = d->ctx;
+    TSU_REQUIRE(ctx, n_replicas >= 1 && temperatures && states_host && seeds && sweep0s && replicas,
+                "dense_sweep_replicas: temperatures, states, seeds, sweep0s and replicas are per-replica arrays");
+    TSU_REQUIRE(ctx, n_sweeps >= 0, "dense_sweep: n_sweeps must be >= 0");
+    const int n = d->n;
+    for (int r = 0; r < n_replicas; ++r) {
+        TSU_REQUIRE(ctx, temperatures[r] > 0.0, "Temperature must be positive");
+        for (int i = 0; i < n; ++i)
+            TSU_REQUIRE(ctx, states_host[(size_t)r * n + i] == 0 || states_host[(size_t)r * n + i] == 1, "dense_set_state: state must be 0/1");
+    }
+    if (n_sweeps == 0) return TSU_OK;
+    if (n > DB) {  // larger systems: one replica after the other through the sweep paths
+        for (int r = 0; r < n_replicas; ++r) {
+            int rc = tsu_dense_set_state(d, states_host + (size_t)r * n);
+            if (rc == TSU_OK)
+                rc = tsu_dense_sweep(d, temperatures[r], n_sweeps, nullptr, seeds[r], sweep0s[r], replicas[r],
+                                     replay_uniforms ? replay_uniforms + (size_t)r * n_sweeps * n : nullptr);
+            if (rc == TSU_OK) rc = tsu_dense_get_state(d, states_host + (size_t)r * n);
+            if (rc != TSU_OK) return rc;
+        }
+        return TSU_OK;
+    }
+    const size_t sbytes = (size_t)n_replicas * n, ubytes = replay_uniforms ? (size_t)n_replicas * n_sweeps * n * 8 : 0;
+    const size_t rbytes = (size_t)n_replicas * sizeof(K2Replica);
+    const size_t need = ((sbytes + 7) / 8) * 8 + ubytes + rbytes;
+    if (d->rep_cap < need) {
+        if (d->rep_buf) (void)hipFree(d->rep_buf);
+        d->rep_buf = nullptr;
+        d->rep_cap = 0;
+        TSU_HIP_TRY(ctx, hipMalloc(&d->rep_buf, need));
+        d->rep_cap = need;
+    }
+    int8_t* d_states = (int8_t*)d->rep_buf;
+    double* d_uni = ubytes ? (double*)((char*)d->rep_buf + ((sbytes + 7) / 8) * 8) : nullptr;
+    K2Replica* d_reps = (K2Replica*)((char*)d->rep_buf + ((sbytes + 7) / 8) * 8 + ubytes);
+    std::vector<K2Replica> reps((size_t)n_replicas);
+    for (int r = 0; r < n_replicas; ++r) {
+        reps[(size_t)r].T = temperatures[r];
+        reps[(size_t)r].sweep0 = sweep0s[r];
+        reps[(size_t)r].tag = TSU_TAG_DENSE | (replicas[r] << 8);
+        reps[(size_t)r].k0 = (uint32_t)seeds[r];
+        reps[(size_t)r].k1 = (uint32_t)(seeds[r] >> 32);
+    }
+    TSU_HIP_TRY(ctx, hipMemcpyAsync(d_states, states_host, sbytes, hipMemcpyHostToDevice, ctx->stream));
+    if (ubytes) TSU_HIP_TRY(ctx, hipMemcpyAsync(d_uni, replay_uniforms, ubytes, hipMemcpyHostToDevice, ctx->stream));
+    TSU_HIP_TRY(ctx, hipMemcpyAsync(d_reps, reps.data(), rbytes, hipMemcpyHostToDevice, ctx->stream));
+    if (d->dtype == TSU_DTYPE_F64)
+        k2_small_replicas<double><<<(unsigned)n_replicas, 64, 0, ctx->stream>>>((const double*)d->J, d->bias, d_states, d_uni, d_reps, n, n_sweeps);
+    else
+        k2_small_replicas<float><<<(unsigned)n_replicas, 64, 0, ctx->stream>>>((const float*)d->J, d->bias, d_states, d_uni, d_reps, n, n_sweeps);
+    TSU_HIP_TRY(ctx, hipGetLastError());
+    TSU_HIP_TRY(ctx, hipMemcpyAsync(states_host, d_states, sbytes, hipMemcpyDeviceToHost, ctx->stream));
+    TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TSU_OK;
 }
 
 int tsu_dense_energy(tsu_dense* d, double* energy) {

@@ -79,6 +79,7 @@ SIGNATURES = {
     "tsu_dense_sweep": (C.c_int, [_vp, C.c_double, C.c_int, _i64p, C.c_uint64, C.c_uint32, C.c_uint32, _f64p]),
     "tsu_dense_sample": (C.c_int, [_vp, C.c_double, C.c_int, C.c_int, C.c_int, _i64p, C.c_uint64, C.c_uint32, C.c_uint32, _f64p, _i8p]),
     "tsu_dense_anneal": (C.c_int, [_vp, _f64p, C.c_int, _i64p, C.c_uint64, C.c_uint32, C.c_uint32, _f64p, _i8p]),
+    "tsu_dense_sweep_replicas": (C.c_int, [_vp, C.c_int, _f64p, C.c_int, _i8p, _u64p, _u32p, _u32p, _f64p]),
     "tsu_dense_energy": (C.c_int, [_vp, _f64p]),
     "tsu_langevin_create": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)]),
     "tsu_langevin_destroy": (C.c_int, [_vp]),
@@ -378,6 +379,19 @@ class DenseSystem:
         self.ctx.check(self.lib.tsu_dense_anneal(self.h, _ptr(t, _f64p), steps, None if o is None else _ptr(o, _i64p), int(seed),
                                                  int(sweep0), int(replica), None if u is None else _ptr(u, _f64p), _ptr(out, _i8p)))
         return out
+
+    def sweep_replicas(self, states, temperatures, n_sweeps, seeds, sweep0s, replicas=None, replay_uniforms=None):
+        """n_sweeps sweeps of every replica state (rows of ``states``) at its own temperature: (R, n) int8 of 0/1."""
+        st = np.ascontiguousarray(states, dtype=np.int8).reshape(-1, self.n).copy()
+        R = st.shape[0]
+        t = np.ascontiguousarray(temperatures, dtype=np.float64).reshape(R)
+        sd = np.ascontiguousarray(seeds, dtype=np.uint64).reshape(R)
+        s0 = np.ascontiguousarray(sweep0s, dtype=np.uint32).reshape(R)
+        rp = np.zeros(R, dtype=np.uint32) if replicas is None else np.ascontiguousarray(replicas, dtype=np.uint32).reshape(R)
+        u = None if replay_uniforms is None else np.ascontiguousarray(replay_uniforms, dtype=np.float64).reshape(R, int(n_sweeps), self.n)
+        self.ctx.check(self.lib.tsu_dense_sweep_replicas(self.h, R, _ptr(t, _f64p), int(n_sweeps), _ptr(st, _i8p), _ptr(sd, _u64p),
+                                                         _ptr(s0, _u32p), _ptr(rp, _u32p), None if u is None else _ptr(u, _f64p)))
+        return st
 
     def energy(self):
         e = C.c_double(0)

@@ -249,16 +249,15 @@ class GibbsSampler:
             rep = GibbsSampler(cfg, rng=self.rng, seed=None if self.rng == "numpy" else self._philox_seed() + len(samplers) + 1,
                                coupling_dtype="float64" if self._dtype == _hip.DTYPE_F64 else "float32")
             samplers.append(rep)
-        for i, sampler in enumerate(samplers):
-            states[i] = sampler.gibbs_sweep(states[i], coupling, bias, n_sweeps=self.config.n_burnin)
+        states = self._sweep_replicas(samplers, states, coupling, bias, self.config.n_burnin)
         samples = []
         swap_attempts = 0
         swap_accepts = 0
         energies_history = [[] for _ in range(n_replicas)]
         sweep_count = 0
         while len(samples) < n_samples:
-            for i, sampler in enumerate(samplers):
-                states[i] = sampler.gibbs_sweep(states[i], coupling, bias, n_sweeps=self.config.n_sweeps)
+            states = self._sweep_replicas(samplers, states, coupling, bias, self.config.n_sweeps)
+            for i in range(n_replicas):
                 energies_history[i].append(energy_of(states[i]))
             sweep_count += 1
             if sweep_count % swap_interval == 0:
@@ -282,6 +281,31 @@ class GibbsSampler:
         for s in samplers:
             s.invalidate()
         return samples, info
+
+    def _sweep_replicas(self, samplers, states, coupling, bias, n_sweeps):
+        """The replica loop of parallel_tempering (reference: gibbs.py:300-306): every replica's sweeps in ONE device
+        call for systems of up to 64 sites in sequential order (one wave per replica); otherwise replica by replica.
+        Draws (np.random uniforms / each replica's Philox counters) are consumed exactly as in the one-by-one loop."""
+        n_sweeps = int(n_sweeps)
+        n_bits = np.asarray(coupling).shape[0]
+        if n_sweeps <= 0:
+            return states
+        if n_bits > 64 or self.config.update_order != "sequential":
+            return [s.gibbs_sweep(st, coupling, bias, n_sweeps=n_sweeps) for s, st in zip(samplers, states)]
+        sys = self._system(coupling, bias)
+        temps = [float(s.config.temperature) for s in samplers]
+        for T in temps:
+            if T <= 0:
+                raise ValueError("Temperature must be positive")
+        bits = np.array([self._as_bits(st, n_bits) for st in states], dtype=np.int8)
+        if self.rng == "numpy":
+            uni = np.array([np.random.rand(n_sweeps, n_bits) for _ in samplers])
+            out = sys.sweep_replicas(bits, temps, n_sweeps, [0] * len(samplers), [0] * len(samplers), replay_uniforms=uni)
+        else:
+            out = sys.sweep_replicas(bits, temps, n_sweeps, [s._philox_seed() for s in samplers], [s._sweep_counter for s in samplers])
+            for s in samplers:
+                s._sweep_counter += n_sweeps
+        return [out[i].astype(np.asarray(states[i]).dtype) for i in range(len(samplers))]
 
     def simulated_annealing(self, coupling: np.ndarray, bias: Optional[np.ndarray] = None, T_initial: float = 10.0,
                             T_final: float = 0.1, n_steps: int = 1000,
