@@ -254,6 +254,31 @@ def test_ising_model2d_facade_and_onsager():
         IsingModel2D(8, temperature=0)
 
 
+def test_onsager_on_the_tile_resident_kernel():
+    """Physics check of the kernels that bench.py measures (tiles resident in LDS, strips exchanged between tiles), on a
+    lattice large enough for sharp values: 1024 x 1024 at T = 2.0 < T_c from a cold start.  Exact infinite-lattice
+    results: M = (1 - sinh(2/T)^-4)^(1/8) = 0.911319, u = -1.745565 (Onsager); both bias conventions agree at h = 0
+    only in physical mode, which is what the facade uses."""
+    from tsu.models.ising import IsingModel2D
+    m = IsingModel2D(size=1024, temperature=2.0, seed=123, initial="up")
+    m.equilibrate(n_sweeps=2000)
+    ms, es = [], []
+    for _ in range(30):
+        m.gibbs_update(50)
+        ms.append(m.magnetization())
+        es.append(m.energy() / m.n_spins)
+    assert abs(np.mean(ms) - 0.911319) < 0.002
+    assert abs(np.mean(es) + 1.745565) < 0.003
+    # an open lattice of the same size: the bulk values with an O(1/L) surface correction (fewer bonds at the edge)
+    mo = IsingModel2D(size=1024, temperature=2.0, seed=124, initial="up", periodic=False)
+    mo.equilibrate(n_sweeps=2000)
+    eo = []
+    for _ in range(10):
+        mo.gibbs_update(50)
+        eo.append(mo.energy() / mo.n_spins)
+    assert -1.745565 < np.mean(eo) < -1.745565 + 0.02
+
+
 # ============================================================================ tsu.core
 def test_core_gaussian_sampling_like_the_reference_suite():
     from scipy import stats
