@@ -685,7 +685,7 @@ int tsu_ising2d_observables(tsu_ising2d* L, int64_t* sum_s, int64_t* sum_bonds) 
     K1Params p = make_params(L, L->alloc[L->cur]);
     TSU_HIP_TRY(ctx, hipMemsetAsync(L->d_obs, 0, 2 * sizeof(int64_t), ctx->stream));
     long long work = (long long)L->rows * ((L->cols + 15) / 16);
-    unsigned blocks = (unsigned)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096);
+    unsigned blocks = (unsigned)((work + 255) / 256 < 512 ? (work + 255) / 256 : 512);  // one atomic pair per block: keep them few (14 ns each, serialised)
     k4_observables<<<blocks, 256, 0, ctx->stream>>>(p, (long long*)L->d_obs);
     TSU_HIP_TRY(ctx, hipGetLastError());
     int64_t h[2];
@@ -791,7 +791,7 @@ int tsu_ising2d_observables_batch(tsu_ising2d* const* lats, int n_lats, int64_t*
         K1Params p = make_params(L, L->alloc[L->cur]);
         TSU_HIP_TRY(ctx, hipMemsetAsync(L->d_obs, 0, 2 * sizeof(int64_t), ctx->stream));
         long long work = (long long)L->rows * ((L->cols + 15) / 16);
-        unsigned blocks = (unsigned)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096);
+        unsigned blocks = (unsigned)((work + 255) / 256 < 512 ? (work + 255) / 256 : 512);  // one atomic pair per block: keep them few (14 ns each, serialised)
         k4_observables<<<blocks, 256, 0, ctx->stream>>>(p, (long long*)L->d_obs);
         TSU_HIP_TRY(ctx, hipMemcpyAsync(&h[(size_t)2 * i], L->d_obs, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     }
