@@ -134,7 +134,8 @@ int tsu_ising2d_sample(tsu_ising2d* lat, int n_burnin, int n_sweeps, int n_sampl
 /* Many independent lattices at once (one per temperature of a scan, ising.py:424-476; replicas of a tempering
  * ladder): lattice i does n_sweeps sweeps with its own thresholds, seeds[i], sweep0s[i], replicas[i] -- the same
  * results as n calls of tsu_ising2d_sweep.  Lattices that fit the one-workgroup kernel (TSU_KERNEL_SMALL) run as ONE
- * launch, one workgroup each; others are swept one after the other.  observables_batch: one synchronisation for all. */
+ * launch, one workgroup each; larger ones go to a few side streams and run side by side as far as they fit the chip
+ * together.  observables_batch: one synchronisation for all. */
 int tsu_ising2d_sweep_batch(tsu_ising2d* const* lats, int n_lats, int n_sweeps, const uint64_t* seeds,
                             const uint32_t* sweep0s, const uint32_t* replicas);
 int tsu_ising2d_observables_batch(tsu_ising2d* const* lats, int n_lats, int64_t* sum_s, int64_t* sum_bonds);

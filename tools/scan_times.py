@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np
 from tsu.models.ising import temperature_scan, IsingModel2D
 Ts = np.linspace(1.5, 3.5, 32)
-for size in (32, 64, 128):
+for size in (32, 64, 128, 512, 1024):
     temperature_scan(size, Ts[:2], n_equilibrate=10, n_measure=2)
     t0 = time.perf_counter()
     r = temperature_scan(size, Ts, n_equilibrate=2000, n_measure=50, measure_every=10, seed=5)

@@ -32,5 +32,6 @@ struct tsu_ising2d {
 
 // ising2d_tiled.hip
 int tsu_ising2d_tiled_supported(const tsu_ising2d* L);
+int tsu_ising2d_tiled_tiles(const tsu_ising2d* L);
 int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_t sweep0, uint32_t replica, int part);
 int tsu_ising2d_tiled_part_supported(const tsu_ising2d* L);

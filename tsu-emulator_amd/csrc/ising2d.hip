@@ -741,11 +741,44 @@ int tsu_ising2d_sweep_batch(tsu_ising2d* const* lats, int n_lats, int n_sweeps, 
     }
     if (n_sweeps == 0) return TSU_OK;
     if (!one_launch) {
-        for (int i = 0; i < n_lats; ++i) {
-            const int rc = tsu_ising2d_sweep(lats[i], n_sweeps, seeds[i], sweep0s[i], replicas[i]);
-            if (rc != TSU_OK) return rc;
+        // larger lattices: each lattice's launches go to one of a few side streams, so that lattices which do not fill
+        // the chip on their own (a 1024^2 lattice keeps 128 CUs busy) run side by side.  Fork / join with events
+        // on the context's stream, which therefore sees the batch as one ordered operation.
+        if (ctx->pool_n == 0) {
+            TSU_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
+            for (int i = 0; i < 8; ++i) {
+                TSU_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->pool[i], hipStreamNonBlocking));
+                TSU_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->pool_ev[i], hipEventDisableTiming));
+                ctx->pool_n = i + 1;
+            }
         }
-        return TSU_OK;
+        hipStream_t main_stream = ctx->stream;
+        TSU_HIP_TRY(ctx, hipEventRecord(ctx->fork_ev, main_stream));
+        // Tile-resident launches wait inside the kernel for all of their workgroups: never have more of them in flight
+        // than fit the chip together (one workgroup per CU counted), or two half-placed grids could wait for each other.
+        int max_tiles = 0;
+        for (int i = 0; i < n_lats; ++i) {
+            const int t = tsu_ising2d_tiled_tiles(lats[i]);
+            if (t > max_tiles) max_tiles = t;
+        }
+        int used = n_lats < ctx->pool_n ? n_lats : ctx->pool_n;
+        if (max_tiles > 0) {
+            const int fit = ctx->cus / max_tiles;
+            if (used > fit) used = fit < 1 ? 1 : fit;
+        }
+        for (int i = 0; i < used; ++i) TSU_HIP_TRY(ctx, hipStreamWaitEvent(ctx->pool[i], ctx->fork_ev, 0));
+        int rc = TSU_OK;
+        for (int i = 0; i < n_lats && rc == TSU_OK; ++i) {
+            ctx->stream = ctx->pool[i % used];
+            rc = tsu_ising2d_sweep(lats[i], n_sweeps, seeds[i], sweep0s[i], replicas[i]);
+        }
+        ctx->stream = main_stream;
+        for (int i = 0; i < used; ++i) {
+            hipError_t e = hipEventRecord(ctx->pool_ev[i], ctx->pool[i]);
+            if (e == hipSuccess) e = hipStreamWaitEvent(main_stream, ctx->pool_ev[i], 0);
+            if (e != hipSuccess && rc == TSU_OK) rc = tsu_fail(ctx, TSU_E_HIP, "ising2d_sweep_batch: %s", hipGetErrorString(e));
+        }
+        return rc;
     }
     std::vector<K1BatchItem> items((size_t)n_lats);
     for (int i = 0; i < n_lats; ++i) {

@@ -657,6 +657,13 @@ int tsu_ising2d_tiled_supported(const tsu_ising2d* L) {
     return 1;
 }
 
+// number of tiles (= workgroups of a tile-resident launch) the lattice is cut into; 0 if the tiled kernel does not apply
+int tsu_ising2d_tiled_tiles(const tsu_ising2d* L) {
+    if (!tsu_ising2d_tiled_supported(L)) return 0;
+    const TileVariant& tv = kVariants[pick_variant(L)];
+    return ((L->rows + tv.H - 1) / tv.H) * ((L->cols / 16 + tv.WO - 1) / tv.WO);
+}
+
 // split (interior / boundary) launches: ghost-row slabs whose tile rows are all full
 int tsu_ising2d_tiled_part_supported(const tsu_ising2d* L) {
     return tsu_ising2d_tiled_supported(L) && !L->wrap_rows && (L->rows % kVariants[pick_variant(L)].H) == 0;

@@ -13,6 +13,11 @@ struct tsu_ctx {
     hipEvent_t ev0, ev1;
     char err[512];
     int cus;
+    // side streams for batches of independent lattices (tsu_ising2d_sweep_batch), created on first use
+    hipStream_t pool[8];
+    hipEvent_t pool_ev[8];
+    hipEvent_t fork_ev;
+    int pool_n;
 };
 
 extern thread_local char g_tsu_init_err[512];

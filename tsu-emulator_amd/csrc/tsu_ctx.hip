@@ -45,6 +45,7 @@ int tsu_init(int device, tsu_ctx** out) {
         return tsu_fail(nullptr, TSU_E_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
     }
     ctx->cus = prop.multiProcessorCount;
+    ctx->pool_n = 0;
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
         delete ctx;
         return tsu_fail(nullptr, TSU_E_HIP, "hipEventCreate failed");
@@ -59,6 +60,12 @@ int tsu_shutdown(tsu_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
+    for (int i = 0; i < ctx->pool_n; ++i) {
+        (void)hipStreamSynchronize(ctx->pool[i]);
+        (void)hipStreamDestroy(ctx->pool[i]);
+        (void)hipEventDestroy(ctx->pool_ev[i]);
+    }
+    if (ctx->pool_n) (void)hipEventDestroy(ctx->fork_ev);
     delete ctx;
     return TSU_OK;
 }
