@@ -462,6 +462,10 @@ static int coop_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint3
         const char* ev = getenv("TSU_K2_COOP_LAUNCH");
         coop_api = ev ? atoi(ev) : 0;
     }
+    {
+        const int rcx = tsu_grid_exclusive_begin(ctx);
+        if (rcx != TSU_OK) return rcx;
+    }
     hipError_t e;
     if (coop_api) {
         void* args[] = {&P};
@@ -474,6 +478,10 @@ static int coop_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint3
         (void)hipGetLastError();
         d->co_disabled = 1;
         return TSU_OK;
+    }
+    {
+        const int rcx = tsu_grid_exclusive_end(ctx);
+        if (rcx != TSU_OK) return rcx;
     }
     unsigned h[4];  // [1] = error flag, [2] = slowest fixed point, [3] = not-converged flag
     TSU_HIP_TRY(ctx, hipMemcpyAsync(h + 1, d->co_bar + BAR_ERR, 3 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));

@@ -768,10 +768,12 @@ int tsu_ising2d_sweep_batch(tsu_ising2d* const* lats, int n_lats, int n_sweeps, 
         }
         for (int i = 0; i < used; ++i) TSU_HIP_TRY(ctx, hipStreamWaitEvent(ctx->pool[i], ctx->fork_ev, 0));
         int rc = TSU_OK;
+        ctx->in_batch = 1;
         for (int i = 0; i < n_lats && rc == TSU_OK; ++i) {
             ctx->stream = ctx->pool[i % used];
             rc = tsu_ising2d_sweep(lats[i], n_sweeps, seeds[i], sweep0s[i], replicas[i]);
         }
+        ctx->in_batch = 0;
         ctx->stream = main_stream;
         for (int i = 0; i < used; ++i) {
             hipError_t e = hipEventRecord(ctx->pool_ev[i], ctx->pool[i]);

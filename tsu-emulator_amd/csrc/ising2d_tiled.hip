@@ -842,11 +842,19 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
                 if (vb)
                     fprintf(stderr, "[tsu] k1_resident variant %d: %d tiles (%d per CU fit), %d generations of %d sweeps, %zu KB of strips\n",
                             vi, ntiles, fit_per_cu, P.r.n_gen, kmax, xneed * 8 / 1024);
+                {
+                    const int rcx = tsu_grid_exclusive_begin(ctx);
+                    if (rcx != TSU_OK) return rcx;
+                }
                 TSU_HIP_TRY(ctx, hipMemsetAsync(L->d_sync, 0, (size_t)ntiles * sizeof(int), ctx->stream));
                 hipLaunchKernelGGL(res_kern, dim3((unsigned)ntiles), dim3((unsigned)tv.threads), lds_bytes, ctx->stream, P);
                 L->launches += 1;
                 L->cur ^= 1;
                 TSU_HIP_TRY(ctx, hipGetLastError());
+                {
+                    const int rcx = tsu_grid_exclusive_end(ctx);
+                    if (rcx != TSU_OK) return rcx;
+                }
                 if (d_dbg) {
                     long long h[4];
                     (void)hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost);

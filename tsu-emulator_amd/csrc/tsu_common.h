@@ -18,7 +18,15 @@ struct tsu_ctx {
     hipEvent_t pool_ev[8];
     hipEvent_t fork_ev;
     int pool_n;
+    int in_batch;  // inside tsu_ising2d_sweep_batch: the batch itself bounds how many co-resident grids are in flight
 };
+
+// Kernels that synchronise inside the grid (k1_resident, k2_coop) need all their workgroups on the chip at once.  Two
+// of them launched on different streams of this process could each get part of the chip and wait for the rest, so
+// such launches are chained per device: begin() makes the stream wait for the previous such launch, end() records
+// this one.  (Across processes nothing can be chained: see DESIGN.md, honest gaps.)
+int tsu_grid_exclusive_begin(tsu_ctx* ctx);
+int tsu_grid_exclusive_end(tsu_ctx* ctx);
 
 extern thread_local char g_tsu_init_err[512];
 

@@ -14,6 +14,29 @@ int tsu_fail(tsu_ctx* ctx, int code, const char* fmt, ...) {
     return code;
 }
 
+namespace {
+constexpr int kMaxDevices = 64;
+hipEvent_t g_grid_ev[kMaxDevices];
+bool g_grid_ev_made[kMaxDevices];
+}  // namespace
+
+int tsu_grid_exclusive_begin(tsu_ctx* ctx) {
+    if (ctx->in_batch || ctx->device < 0 || ctx->device >= kMaxDevices) return TSU_OK;
+    if (!g_grid_ev_made[ctx->device]) {
+        TSU_HIP_TRY(ctx, hipEventCreateWithFlags(&g_grid_ev[ctx->device], hipEventDisableTiming));
+        g_grid_ev_made[ctx->device] = true;
+        return TSU_OK;  // nothing launched before
+    }
+    TSU_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, g_grid_ev[ctx->device], 0));
+    return TSU_OK;
+}
+
+int tsu_grid_exclusive_end(tsu_ctx* ctx) {
+    if (ctx->in_batch || ctx->device < 0 || ctx->device >= kMaxDevices || !g_grid_ev_made[ctx->device]) return TSU_OK;
+    TSU_HIP_TRY(ctx, hipEventRecord(g_grid_ev[ctx->device], ctx->stream));
+    return TSU_OK;
+}
+
 extern "C" {
 
 int tsu_version(void) { return 100; }
@@ -46,6 +69,7 @@ int tsu_init(int device, tsu_ctx** out) {
     }
     ctx->cus = prop.multiProcessorCount;
     ctx->pool_n = 0;
+    ctx->in_batch = 0;
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
         delete ctx;
         return tsu_fail(nullptr, TSU_E_HIP, "hipEventCreate failed");
