@@ -144,6 +144,34 @@ def test_small_system_distribution_matches_exact_boltzmann_and_reference(golden)
                 assert np.sum((hist - 4000 * p) ** 2 / (4000 * p)) < 40
 
 
+def test_boltzmann_distribution_of_a_frustrated_8_spin_glass_200k_samples():
+    """All 256 states of an 8-bit glass with biases: 200 000 samples (one device call, single-wave kernel) against exact
+    enumeration of exp(-E/T) with E = -1/2 s^T J s - b^T s (gibbs.py:233-236).  Pearson chi-square with 255 degrees of
+    freedom; thinning by 4 sweeps leaves autocorrelation, so the bound is generous (chi2/dof < 2) -- a wrong
+    conditional, visiting order or uniform stream shows up as chi2/dof in the hundreds."""
+    from tsu.gibbs import GibbsSampler, GibbsConfig
+    rng = np.random.default_rng(2024)
+    n, T, N = 8, 1.3, 200_000
+    J = rng.normal(size=(n, n))
+    J = (J + J.T) / 2
+    np.fill_diagonal(J, 0.0)
+    b = rng.normal(size=n) * 0.5
+    np.random.seed(5)
+    s = GibbsSampler(GibbsConfig(temperature=T, n_burnin=200, n_sweeps=4))
+    x = s.sample_boltzmann(J, bias=b, n_samples=N)
+    hist = np.bincount(x.dot(1 << np.arange(n)), minlength=1 << n).astype(float)
+    states = np.array([[(c >> i) & 1 for i in range(n)] for c in range(1 << n)], dtype=float)
+    E = np.array([-0.5 * v @ J @ v - b @ v for v in states])
+    p = np.exp(-(E - E.min()) / T)
+    p /= p.sum()
+    keep = N * p >= 5
+    chi2 = np.sum((hist[keep] - N * p[keep]) ** 2 / (N * p[keep]))
+    assert chi2 / keep.sum() < 2.0, chi2 / keep.sum()
+    # and the means: <s_i> within 5 standard errors (inflated x3 for autocorrelation)
+    mean_exact = p @ states
+    assert np.all(np.abs(x.mean(0) - mean_exact) < 15 * np.sqrt(0.25 / N))
+
+
 # ============================================================================ tsu.models.ising
 def test_ising_model_sampling_shapes_and_phases():
     from tsu.models import IsingChain, IsingGrid, IsingModel
