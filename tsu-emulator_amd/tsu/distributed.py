@@ -6,9 +6,11 @@ The reference has no parallelism of any kind; this is new 
 Rank r owns rows [r*R, (r+1)*R) of a (P*R) x cols lattice plus ``ghost = 2S`` ghost rows on each side.  Every S
 sweeps (``sweeps_per_exchange``) the ranks exchange their 2S boundary rows with the rank above and below
 (``torch.distributed`` point-to-point, i.e. RCCL send/recv over xGMI with the ``nccl`` backend): one exchange per
-S sweeps instead of two per sweep, because each half-sweep consumes one ghost row.  S may span several kernel
-launches: between two exchanges a slab keeps its own halo exact by also sweeping the ghost rows the later launches
-will read (2 rows per remaining sweep; < 1 % extra work), so the message latency is paid once per S sweeps.  Philox counters use
+S sweeps instead of two per sweep, because each half-sweep consumes one ghost row.  S spans several generations of k
+sweeps: between two exchanges a slab keeps its own halo exact by also sweeping the ghost rows the later generations
+will read (2 rows per remaining sweep; a few % extra work), so the message latency is paid once per S sweeps, and --
+when every tile of the slab has its own workgroup on the GPU, as for 4096 x 4096 per GPU -- the whole period is ONE
+launch with the tiles resident in LDS (csrc/ising2d_tiled.hip, k1_resident).  Philox counters use
 GLOBAL (row, column, sweep) coordinates, so the trajectory is bit-identical for every P (tested).
 
 Optional overlap (``overlap=True``, S <= 8): the tile rows that do not touch ghost rows are swept on the compute
