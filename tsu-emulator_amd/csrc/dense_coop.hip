@@ -75,16 +75,19 @@ struct GridBar {
 };
 
 static __device__ __forceinline__ bool bar_wait(unsigned* bar, const unsigned* word, unsigned target) {
+    // one agent-scope load per poll (the load's own latency is the back-off); the error flag and the clock are looked at
+    // every 64th poll only -- checking them every time doubled the time a barrier takes to release
     const long long t0 = wall_clock64();
-    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(1);
-        if (__hip_atomic_load(&bar[BAR_ERR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
-        if (wall_clock64() - t0 > CO_TIMEOUT) {
-            __hip_atomic_store(&bar[BAR_ERR], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return false;
+    for (unsigned spins = 0;; ++spins) {
+        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+        if ((spins & 63u) == 63u) {
+            if (__hip_atomic_load(&bar[BAR_ERR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+            if (wall_clock64() - t0 > CO_TIMEOUT) {
+                __hip_atomic_store(&bar[BAR_ERR], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
         }
     }
-    return true;
 }
 
 // once per kernel: which XCD am I on, how many workgroups share it, how many XCDs take part (one flat barrier)
