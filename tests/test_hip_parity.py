@@ -94,6 +94,35 @@ def test_ising2d_tiled_kernel_bit_exact(hip, rows, cols, spl, periodic):
         lat.close()
 
 
+@pytest.mark.parametrize("rows,cols,spl", [(100, 289, 3), (96, 290, 8), (130, 295, 5), (128, 300, 8), (97, 303, 2), (200, 1000, 8),
+                                           (256, 1017, 8), (128, 1023, 4), (1000, 1000, 0), (512, 2040, 0)])
+def test_ising2d_tiled_open_lattice_of_any_width(hip, rows, cols, spl):
+    """Open lattices whose width is not a multiple of 16 (the reference's default boundary, any size: IsingGrid((1000, 1000))):
+    the last 16-byte chunk of a row is ragged; the sites beyond the last column do not exist, the last column has degree 3,
+    the row's pad bytes stay 0.  Tiled kernel == oracle, including the tie path (coarse table)."""
+    seed = 31 + rows + cols
+    s0 = ora.ising2d_randomize(rows, cols, seed)
+    tables = [ora.ising2d_thresholds(1.0, 0.1, 2.0, hip.MODE_PHYSICAL),
+              np.array([(k * 0x0A3D) << 16 | 0x8000 for k in range(25)], dtype=np.uint64)]
+    for table in tables:
+        lat = hip.Lattice(rows, cols, False)
+        if spl:
+            lat.set_kernel(hip.KERNEL_TILED, spl)
+        lat.set_spins(s0)
+        lat.set_thresholds(table)
+        n0 = lat.launch_count()
+        lat.sweep(19, seed, sweep0=2)
+        assert lat.launch_count() - n0 <= -(-19 // (spl or 8))  # the tiled kernel, also when the library chooses (generic: 38 launches)
+        want = ora.ising2d_sweep(s0, False, table, 19, seed, sweep0=2)
+        np.testing.assert_array_equal(lat.get_spins(), want)
+        assert lat.observables() == ora.ising2d_observables(want, False)
+        # pad bytes untouched: a generic-kernel sweep afterwards (it reads whole chunks) still agrees
+        lat.set_kernel(hip.KERNEL_GENERIC)
+        lat.sweep(2, seed, sweep0=21)
+        np.testing.assert_array_equal(lat.get_spins(), ora.ising2d_sweep(want, False, table, 2, seed, sweep0=21))
+        lat.close()
+
+
 def test_ising2d_tiled_ties_and_clamps(hip):
     """Coarse / extreme threshold tables drive the tiled kernel's tie path (low 16 bits) and the 0 / 2^32 clamps."""
     rows, cols = 128, 1040

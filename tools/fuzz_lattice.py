@@ -8,6 +8,9 @@ for case in range(int(os.environ.get("FUZZ_CASES", "60"))):
     rows = random.choice([96, 128, 192, 256, 320, 512, 1024, 2048, 3072])
     cols = random.choice([288, 320, 512, 544, 768, 1024, 1536, 2048, 4096])
     periodic = random.random() < 0.6
+    if not periodic and random.random() < 0.6:  # open lattices: any width / height
+        cols = random.randint(288, 2100)
+        rows = random.randint(96, 1100)
     if periodic and (rows % 2 or cols % 2):
         continue
     k = random.choice([0, 1, 3, 5, 8])

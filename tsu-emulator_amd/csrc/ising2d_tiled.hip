@@ -23,7 +23,8 @@ struct TiledParams {
     const int8_t* src;  // owned row 0 of the source buffer
     int8_t* dst;        // owned row 0 of the destination buffer
     long long pitch;
-    int rows, nchunks;           // owned rows; cols / 16
+    int rows, nchunks;           // owned rows; ceil(cols / 16) (a ragged last chunk only on open lattices)
+    int cols;
     int tile_h;                  // tile height of this launch (even; the template H is the default and the LDS budget)
     int r_begin, r_end;          // rows this launch computes: [0, rows) or, for a slab that will sweep again before its
                                  // next ghost refresh, [-ext, rows + ext) so that its own halo stays exact
@@ -56,7 +57,7 @@ static __device__ __noinline__ u32x4 resolve_ties(u32x4 d, u32x4 w, uint32_t cnt
                                                   uint32_t cq, uint32_t Rg, uint32_t hs, uint32_t tag_lo, uint32_t k0,
                                                   uint32_t k1, uint32_t edge = 0) {
     // edge (open lattices): bit 0 = the row is the lattice's top or bottom row, bit 1 = site 0 of the octet is in the
-    // lattice's first column, bit 2 = site 7 is in its last column; degree = 4 minus the missing neighbours
+    // lattice's first column, bit 2 = site (edge >> 4) is in its last column; degree = 4 minus the missing neighbours
     const u32x4 l = tsu_philox(cq, Rg, hs, tag_lo, k0, k1);
 #define TSU_FIX(DW, WW, LW, CNT, B0, M0)                                                                        \
     _Pragma("unroll") for (int hlf = 0; hlf < 2; ++hlf) {                                                       \
@@ -64,7 +65,7 @@ static __device__ __noinline__ u32x4 resolve_ties(u32x4 d, u32x4 w, uint32_t cnt
         if (((DW >> sh) & 0xFFFFu) == 0) {                                                                      \
             const uint32_t c = (CNT >> (8 * (B0 + hlf))) & 0xFFu;                                               \
             const uint32_t m = M0 + hlf;                                                                        \
-            const uint32_t deg = 4u - (edge & 1u) - ((m == 0 && (edge & 2u)) ? 1u : 0u) - ((m == 7 && (edge & 4u)) ? 1u : 0u); \
+            const uint32_t deg = 4u - (edge & 1u) - ((m == 0 && (edge & 2u)) ? 1u : 0u) - ((m == (edge >> 4) && (edge & 4u)) ? 1u : 0u); \
             const uint64_t u = ((uint64_t)(((WW >> sh) & 0xFFFFu) ^ 0x8000u) << 16) | ((LW >> sh) & 0xFFFFu);   \
             const uint32_t f = (u < s_thr[deg * 5 + c]) ? 0x8000u : 0x0001u; /* negative field = accept */      \
             DW = (DW & ~(0xFFFFu << sh)) | (f << sh);                                                           \
@@ -129,7 +130,9 @@ struct Rows2Ctx {
     uint32_t t3H0, t3H1, t3L0, t3L1;  // open lattices: degree 3 / degree 2 byte tables
     int last_row;                     // open lattices: global index of the lattice's bottom row
     bool lft, rgt;                    // open lattices: this thread's octet holds the lattice's first / last column
-    bool col_out;                     // open lattices: this thread's octet lies beyond the lattice (stays empty)
+    uint32_t r_par, r_slot;           // open lattices: column parity of the last column and its site within the octet
+    uint32_t rm_lo, rm_hi;            // 0xFF at that site's byte
+    uint64_t vm_e, vm_o;              // open lattices: 0x01 for the even / odd columns of this octet that exist
 };
 
 // thresholds for the 8 sites of one octet given their up-counts, compared with one Philox block: d < 0 = accept
@@ -146,16 +149,18 @@ static __device__ __forceinline__ u32x4 compare_octet(const u32x4& w, uint32_t c
 }
 
 // Open lattices: as compare_octet, then the sites with fewer than four neighbours take their thresholds from the
-// degree-3 / degree-2 table instead (row_edge: the whole row is the lattice's top or bottom row; l0 / r7: site 0 /
-// site 7 of the octet sits in the lattice's first / last column).  Only executed by waves that hold such a site.
+// degree-3 / degree-2 table instead (row_edge: the whole row is the lattice's top or bottom row; l0: site 0 of the octet
+// sits in the lattice's first column; r7: site c.r_slot sits in its last column -- site 7 unless the width is ragged).  Only executed by waves that hold such a site.
 static __device__ __forceinline__ u32x4 compare_octet_open(const u32x4& w, uint32_t cnt_lo, uint32_t cnt_hi, const Rows2Ctx& c,
                                                            bool row_edge, bool l0, bool r7) {
     uint32_t Hl = perm(c.tblH1, c.tblH0, cnt_lo), Ll = perm(c.tblL1, c.tblL0, cnt_lo);
     uint32_t Hh = perm(c.tblH1, c.tblH0, cnt_hi), Lh = perm(c.tblL1, c.tblL0, cnt_hi);
     if (row_edge | l0 | r7) {
         // entries 0..3 = degree 3, 4..6 = degree 2 (a corner: edge row and edge column)
-        const uint32_t il = cnt_lo + ((row_edge && l0) ? 0x00000004u : 0u), ih = cnt_hi + ((row_edge && r7) ? 0x04000000u : 0u);
-        const uint32_t ml = row_edge ? 0xFFFFFFFFu : (l0 ? 0x000000FFu : 0u), mh = row_edge ? 0xFFFFFFFFu : (r7 ? 0xFF000000u : 0u);
+        const uint32_t rl = r7 ? c.rm_lo : 0u, rh = r7 ? c.rm_hi : 0u;
+        const uint32_t il = cnt_lo + ((row_edge && l0) ? 0x00000004u : 0u) + (row_edge ? (rl & 0x04040404u) : 0u);
+        const uint32_t ih = cnt_hi + (row_edge ? (rh & 0x04040404u) : 0u);
+        const uint32_t ml = row_edge ? 0xFFFFFFFFu : ((l0 ? 0x000000FFu : 0u) | rl), mh = row_edge ? 0xFFFFFFFFu : rh;
         Hl = (Hl & ~ml) | (perm(c.t3H1, c.t3H0, il) & ml);
         Ll = (Ll & ~ml) | (perm(c.t3L1, c.t3L0, il) & ml);
         Hh = (Hh & ~mh) | (perm(c.t3H1, c.t3H0, ih) & mh);
@@ -226,13 +231,13 @@ static __device__ __forceinline__ void sweep_pairs(const Rows2Ctx& c, const Phil
         uint32_t edge_a = 0, edge_b = 0;
         if (OPEN) {
             // row a updates the columns of parity P0, row b those of parity 1 - P0: the lattice's first column is site 0
-            // of octet 0 for parity 0, its last column site 7 of the last octet for parity 1
+            // of octet 0 for parity 0, its last column site r_slot of the last octet for parity r_par
             const bool ea = rga == 0 || rga == c.last_row, eb = rgb == 0 || rgb == c.last_row;
-            const bool la = !P0 && c.lft, ra = P0 && c.rgt, lb = P0 && c.lft, rb = !P0 && c.rgt;
+            const bool la = !P0 && c.lft, ra = c.rgt && c.r_par == (uint32_t)P0, lb = P0 && c.lft, rb = c.rgt && c.r_par != (uint32_t)P0;
             d0 = compare_octet_open(w0, cnt0l, cnt0h, c, ea, la, ra);
             d1 = compare_octet_open(w1, cnt1l, cnt1h, c, eb, lb, rb);
-            edge_a = (ea ? 1u : 0u) | (la ? 2u : 0u) | (ra ? 4u : 0u);
-            edge_b = (eb ? 1u : 0u) | (lb ? 2u : 0u) | (rb ? 4u : 0u);
+            edge_a = (ea ? 1u : 0u) | (la ? 2u : 0u) | (ra ? 4u : 0u) | (c.r_slot << 4);
+            edge_b = (eb ? 1u : 0u) | (lb ? 2u : 0u) | (rb ? 4u : 0u) | (c.r_slot << 4);
         } else {
             d0 = compare_octet(w0, cnt0l, cnt0h, c.tblH0, c.tblH1, c.tblL0, c.tblL1);
             d1 = compare_octet(w1, cnt1l, cnt1h, c.tblH0, c.tblH1, c.tblL0, c.tblL1);
@@ -245,8 +250,8 @@ static __device__ __forceinline__ void sweep_pairs(const Rows2Ctx& c, const Phil
         char* pd = const_cast<char*>(ps) + d_off;
         uint64_t n0 = pack_flags(d0), n1 = pack_flags(d1);
         if (OPEN) {  // what lies beyond the open edge stays empty (it is a neighbour of the edge sites in the next half-sweep)
-            if (c.col_out || rga < 0 || rga > c.last_row) n0 = 0;
-            if (c.col_out || rgb < 0 || rgb > c.last_row) n1 = 0;
+            n0 = (rga < 0 || rga > c.last_row) ? 0 : (n0 & (P0 ? c.vm_o : c.vm_e));
+            n1 = (rgb < 0 || rgb > c.last_row) ? 0 : (n1 & (P0 ? c.vm_e : c.vm_o));
         }
         *reinterpret_cast<uint64_t*>(pd) = n0;
         *reinterpret_cast<uint64_t*>(pd + NO * 8) = n1;
@@ -310,6 +315,12 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
         if (cqi >= p.nchunks) cqi -= p.nchunks;
     }
     const uint32_t cq = (uint32_t)cqi;
+    // open lattices of ragged width: the columns of this thread's chunk that exist (all 16, fewer in the last chunk, none outside)
+    int nv = OPEN ? p.cols - 16 * cqi : 16;
+    if (col_out) nv = 0;
+    if (nv > 16) nv = 16;
+    auto first_sites = [](int n) { return n >= 8 ? 0x0101010101010101ull : (((1ull << (8 * n)) - 1) & 0x0101010101010101ull); };
+    const uint64_t vm_e = first_sites((nv + 1) >> 1), vm_o = first_sites(nv >> 1);
 
     if (!p.debug && al < RLMAX) {
         const int8_t* col = src + 16 * (long long)(OPEN ? (cqi < 0 ? 0 : (cqi >= p.nchunks ? p.nchunks - 1 : cqi)) : cqi);
@@ -338,7 +349,9 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
                     uint64_t od = (uint64_t)(~(o0 >> 1) & 0x01010101u) | ((uint64_t)(~(o1 >> 1) & 0x01010101u) << 32);
                     if (OPEN) {
                         const long long grow = p.row0 + Rb + tr;
-                        if (col_out || grow < 0 || grow >= p.total_rows) ev = od = 0;  // beyond the open edge: nothing there
+                        if (grow < 0 || grow >= p.total_rows) ev = od = 0;  // beyond the open edge: nothing there
+                        ev &= vm_e;
+                        od &= vm_o;
                     }
                     const int idx = tr * NO + oct;
                     const int gpar = (int)((p.row0 + Rb + tr) & 1);  // colour of the even columns of this row
@@ -366,7 +379,12 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
     c.last_row = (int)p.total_rows - 1;
     c.lft = OPEN && cqi == 0;
     c.rgt = OPEN && cqi == p.nchunks - 1;
-    c.col_out = col_out;
+    c.r_par = (uint32_t)(p.cols - 1) & 1u;
+    c.r_slot = ((uint32_t)(p.cols - 1) & 15u) >> 1;
+    c.rm_lo = c.r_slot < 4 ? 0xFFu << (8 * c.r_slot) : 0u;
+    c.rm_hi = c.r_slot < 4 ? 0u : 0xFFu << (8 * (c.r_slot - 4));
+    c.vm_e = vm_e;
+    c.vm_o = vm_o;
     asm volatile("v_mov_b32 %0, %1" : "=v"(c.tblH0) : "s"(p.tblH0));
     asm volatile("v_mov_b32 %0, %1" : "=v"(c.tblH1) : "s"(p.tblH1));
     asm volatile("v_mov_b32 %0, %1" : "=v"(c.tblL0) : "s"(p.tblL0));
@@ -509,8 +527,15 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
                 // up flag -> spin byte: 1 -> 0x01, 0 -> 0xFF
                 const uint32_t e0 = perm(0u, 0x000001FFu, (uint32_t)ev), e1 = perm(0u, 0x000001FFu, (uint32_t)(ev >> 32));
                 const uint32_t o0 = perm(0u, 0x000001FFu, (uint32_t)od), o1 = perm(0u, 0x000001FFu, (uint32_t)(od >> 32));
-                const uint4 v = make_uint4(perm(o0, e0, 0x05010400u), perm(o0, e0, 0x07030602u), perm(o1, e1, 0x05010400u),
-                                           perm(o1, e1, 0x07030602u));
+                uint4 v = make_uint4(perm(o0, e0, 0x05010400u), perm(o0, e0, 0x07030602u), perm(o1, e1, 0x05010400u),
+                                     perm(o1, e1, 0x07030602u));
+                if (OPEN && nv < 16) {  // ragged last chunk: the pad bytes of the row stay 0
+                    auto bytes = [](int n) { return n >= 4 ? 0xFFFFFFFFu : (n <= 0 ? 0u : (1u << (8 * n)) - 1u); };
+                    v.x &= bytes(nv);
+                    v.y &= bytes(nv - 4);
+                    v.z &= bytes(nv - 8);
+                    v.w &= bytes(nv - 12);
+                }
                 *reinterpret_cast<uint4*>(col + (long long)rl * p.pitch) = v;
             }
             if (RLMAX & 1) gpar ^= 1;
@@ -576,11 +601,11 @@ const TileVariant kVariants[] = {
     {128, 32, 768, k1_tiled2<128, 32, 768, 6>}, // 20: 12 waves per workgroup, 2 workgroups per CU = 6 waves/SIMD
     {128, 32, 640, k1_tiled2<128, 32, 640, 5>}, // 21
     {256, 32, 1024, k1_tiled2<256, 32, 1024, 4>, k1_resident<256, 32, 1024, 4>, k1_tiled2<256, 32, 1024, 4, true>, k1_resident<256, 32, 1024, 4, true>}, // 22: one 148 KB workgroup per CU
-    {128, 16, 1024, k1_tiled2<128, 16, 1024>, k1_resident<128, 16, 1024>},  // 23: narrower tiles for mid-size lattices
+    {128, 16, 1024, k1_tiled2<128, 16, 1024>, k1_resident<128, 16, 1024>, k1_tiled2<128, 16, 1024, 1, true>, k1_resident<128, 16, 1024, 1, true>},  // 23: narrower tiles for mid-size lattices
     {64, 16, 512, k1_tiled2<64, 16, 512>, k1_resident<64, 16, 512>},        // 24
-    {64, 32, 1024, k1_tiled2<64, 32, 1024>, k1_resident<64, 32, 1024>},     // 25
+    {64, 32, 1024, k1_tiled2<64, 32, 1024>, k1_resident<64, 32, 1024>, k1_tiled2<64, 32, 1024, 1, true>, k1_resident<64, 32, 1024, 1, true>},     // 25
     {64, 16, 1024, k1_tiled2<64, 16, 1024>, k1_resident<64, 16, 1024>, k1_tiled2<64, 16, 1024, 1, true>, k1_resident<64, 16, 1024, 1, true>},  // 26
-    {32, 16, 1024, k1_tiled2<32, 16, 1024>, k1_resident<32, 16, 1024>},     // 27
+    {32, 16, 1024, k1_tiled2<32, 16, 1024>, k1_resident<32, 16, 1024>, k1_tiled2<32, 16, 1024, 1, true>, k1_resident<32, 16, 1024, 1, true>},     // 27
     {112, 32, 512, k1_tiled2<112, 32, 512>},      // 23
     {96, 32, 512, k1_tiled2<96, 32, 512, 6>},     // 24
     {160, 32, 512, k1_tiled2<160, 32, 512>},      // 25
@@ -603,27 +628,30 @@ int pick_variant(const tsu_ising2d* L) {
         // waves of the CU in one workgroup; one with ABOUT TWO per CU (2048 x 16384, 4096 x 8192: everything starts
         // and ends together, nothing hides the stage/store phases) does better with 256-row tiles, one per CU
         const int cus = L->ctx->cus > 0 ? L->ctx->cus : 256;
-        const long long tx = (L->cols / 16 + 31) / 32;
+        const long long tx = (((L->cols + 15) / 16) + 31) / 32;
         const long long n128 = ((L->rows + 127) / 128) * tx, n256 = ((L->rows + 255) / 256) * tx;
         if (n128 <= cus) v = 9;
         else if (n128 <= 2 * cus && n256 <= cus && 10 * n256 >= 7 * cus) v = 22;
         else v = 8;
         if (L->rows < 256) v = 6;
-        // Lattices that fit the chip's LDS whole (every tile its own workgroup, tile-resident generations): the tile
-        // shape that finishes a generation of 8 sweeps soonest.  Model fitted to measurements (4096^2, 2048^2, 1024^2,
-        // 4096 x 8192; profiles/r01_k1_experiments.txt): a half-sweep costs 0.25 us + 0.225 us per wave-iteration of the
-        // busiest SIMD, the strip exchange 4.3 us per generation.
+        // Lattices that give every CU at most one tile: the tile shape that finishes a generation of 8 sweeps soonest.
+        // Model fitted to measurements (4096^2, 2048^2, 1024^2, 4096 x 8192, open 1000^2; profiles/r01_k1_experiments.txt):
+        // a half-sweep costs 0.25 us + 0.225 us per wave-iteration of the busiest SIMD; between generations the strip
+        // exchange costs 4.3 us when the tiles stay resident in LDS (the lattice divides into whole tiles), the tile
+        // store + launch gap + stage about 12 us when they do not.
         static const int cand[] = {22, 9, 23, 25, 26, 27};
         double best = 1e30;
         const bool whole = L->ghost == 0 && L->total_rows == L->rows;
+        const int nch = (L->cols + 15) / 16;
         for (int ci = 0; whole && ci < (int)(sizeof(cand) / sizeof(cand[0])); ++ci) {
             const TileVariant& c = kVariants[cand[ci]];
-            if (!(L->periodic ? c.resident : c.resident_open)) continue;
-            if (L->rows % c.H || (L->cols / 16) % c.WO || L->cols / 16 < c.WO + 2 || L->total_rows < c.H + 4 * KMAX) continue;
-            const long long nt = (long long)(L->rows / c.H) * ((L->cols / 16) / c.WO);
+            if (!(L->periodic ? c.kernel : c.open)) continue;
+            if (nch < c.WO + 2 || L->total_rows < c.H + 4 * KMAX) continue;
+            const long long nt = (long long)((L->rows + c.H - 1) / c.H) * ((nch + c.WO - 1) / c.WO);
             if (nt > cus) continue;
+            const bool resident = (L->periodic ? c.resident : c.resident_open) && L->rows % c.H == 0 && nch % c.WO == 0;
             const int pairs = (c.H + 4 * 8 - 2) / 2, waves = (pairs * (c.WO + 2) + 63) / 64;
-            const double t_gen = 16.0 * (0.25 + 0.225 * ((waves + 3) / 4)) + 4.3;
+            const double t_gen = 16.0 * (0.25 + 0.225 * ((waves + 3) / 4)) + (resident ? 4.3 : 12.0);
             if (t_gen < best) {
                 best = t_gen;
                 v = cand[ci];
@@ -633,7 +661,7 @@ int pick_variant(const tsu_ising2d* L) {
     // a variant must fit the lattice (tile not wider than the lattice; single wrap of the global row index) and, for an
     // open lattice, have the OPEN form built; -1 = none does (generic kernel)
     auto fits = [&](int vv) {
-        return L->cols / 16 >= kVariants[vv].WO + 2 && L->total_rows >= kVariants[vv].H + 4 * KMAX && (L->periodic || kVariants[vv].open);
+        return ((L->cols + 15) / 16) >= kVariants[vv].WO + 2 && L->total_rows >= kVariants[vv].H + 4 * KMAX && (L->periodic || kVariants[vv].open);
     };
     if (!fits(v)) {
         static const int fallback[] = {6, 26, 27};
@@ -649,7 +677,7 @@ int pick_variant(const tsu_ising2d* L) {
 }  // namespace
 
 int tsu_ising2d_tiled_supported(const tsu_ising2d* L) {
-    if (L->cols % 16 != 0) return 0;                          // octets must align with 16-byte chunks
+    if (L->cols % 16 != 0 && L->periodic) return 0;           // the wrap must not fall inside an octet (open lattices: any width)
     if (pick_variant(L) < 0) return 0;                        // no tile shape fits (too narrow / too few rows): generic kernel
     const bool open_whole = !L->periodic && L->ghost == 0 && L->total_rows == L->rows;  // beyond its edges: nothing
     if (!L->wrap_rows && !open_whole && L->ghost < 2) return 0;
@@ -661,7 +689,7 @@ int tsu_ising2d_tiled_supported(const tsu_ising2d* L) {
 int tsu_ising2d_tiled_tiles(const tsu_ising2d* L) {
     if (!tsu_ising2d_tiled_supported(L)) return 0;
     const TileVariant& tv = kVariants[pick_variant(L)];
-    return ((L->rows + tv.H - 1) / tv.H) * ((L->cols / 16 + tv.WO - 1) / tv.WO);
+    return ((L->rows + tv.H - 1) / tv.H) * ((((L->cols + 15) / 16) + tv.WO - 1) / tv.WO);
 }
 
 // split (interior / boundary) launches: ghost-row slabs whose tile rows are all full
@@ -697,7 +725,8 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
     TiledParams p;
     p.pitch = (long long)L->pitch;
     p.rows = L->rows;
-    p.nchunks = L->cols / 16;
+    p.nchunks = (L->cols + 15) / 16;
+    p.cols = L->cols;
     p.row0 = L->row0;
     p.total_rows = L->total_rows;
     p.wrap_rows = L->wrap_rows;
