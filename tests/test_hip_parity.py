@@ -123,6 +123,36 @@ def test_ising2d_tiled_open_lattice_of_any_width(hip, rows, cols, spl):
         lat.close()
 
 
+@pytest.mark.parametrize("rows,cols,periodic", [(32, 32, True), (4, 16, True), (128, 128, True), (64, 256, True), (30, 48, True), (4, 4, True), (8, 8, True), (20, 20, True), (50, 50, True), (126, 110, True),
+                                               
+                                                (2, 2, False), (3, 2, False), (50, 50, False), (96, 160, False), (127, 113, False),
+                                                (64, 241, False), (33, 31, False)])
+def test_ising2d_colour_plane_kernel_bit_exact(hip, rows, cols, periodic):
+    """One-workgroup colour-plane kernel (whole lattices of at most 1024 octets: BASELINE configs[0] and the reference's
+    own sizes) == oracle: physical and compat thresholds, a coarse table that drives the tie path, several calls."""
+    seed = 77 + 3 * rows + cols
+    s0 = ora.ising2d_randomize(rows, cols, seed)
+    tables = [ora.ising2d_thresholds(1.0, 0.0, 2.269185, hip.MODE_PHYSICAL), ora.ising2d_thresholds(-0.7, 0.3, 1.1, hip.MODE_COMPAT),
+              np.array([(k * 0x0A3D) << 16 | 0x8000 for k in range(25)], dtype=np.uint64),
+              np.array([0, 1 << 32, 1, (1 << 32) - 1, 65536] * 5, dtype=np.uint64)]
+    for table in tables:
+        lat = hip.Lattice(rows, cols, periodic)
+        lat.set_kernel(hip.KERNEL_SMALL)
+        lat.set_spins(s0)
+        lat.set_thresholds(table)
+        n0 = lat.launch_count()
+        lat.sweep(1, seed, sweep0=0)
+        lat.sweep(30, seed, sweep0=1)
+        assert lat.launch_count() - n0 == 2
+        want = ora.ising2d_sweep(s0, periodic, table, 31, seed, sweep0=0)
+        np.testing.assert_array_equal(lat.get_spins(), want)
+        assert lat.observables() == ora.ising2d_observables(want, periodic)
+        lat.set_kernel(hip.KERNEL_GENERIC)  # pad bytes intact: the generic kernel reads whole chunks
+        lat.sweep(2, seed, sweep0=31)
+        np.testing.assert_array_equal(lat.get_spins(), ora.ising2d_sweep(want, periodic, table, 2, seed, sweep0=31))
+        lat.close()
+
+
 def test_ising2d_tiled_ties_and_clamps(hip):
     """Coarse / extreme threshold tables drive the tiled kernel's tie path (low 16 bits) and the 0 / 2^32 clamps."""
     rows, cols = 128, 1040

@@ -25,6 +25,8 @@ struct tsu_ising2d {
     size_t xbuf_cap;
     void* d_batch;       // tsu_ising2d_sweep_batch: device copy of the per-lattice launch items
     size_t batch_cap;
+    void* d_obs_batch;   // tsu_ising2d_observables_batch: [n][2] sums of the batch (lives with its first lattice)
+    size_t obs_batch_cap;
     size_t sync_cap;     // ints allocated in d_sync
     int* h_err;          // host-mapped flag the tile-resident kernel sets if a bounded wait expires
 };
@@ -35,3 +37,6 @@ int tsu_ising2d_tiled_supported(const tsu_ising2d* L);
 int tsu_ising2d_tiled_tiles(const tsu_ising2d* L);
 int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_t sweep0, uint32_t replica, int part);
 int tsu_ising2d_tiled_part_supported(const tsu_ising2d* L);
+int tsu_ising2d_planes_supported(const tsu_ising2d* L);
+int tsu_ising2d_planes_sweep(tsu_ising2d* const* lats, int n, int n_sweeps, const uint64_t* seeds, const uint32_t* sweep0s,
+                             const uint32_t* replicas);

@@ -448,6 +448,8 @@ int tsu_ising2d_create_slab(tsu_ctx* ctx, int64_t total_rows, int cols, int peri
     L->xbuf_cap = 0;
     L->d_batch = nullptr;
     L->batch_cap = 0;
+    L->d_obs_batch = nullptr;
+    L->obs_batch_cap = 0;
     L->sync_cap = 0;
     L->h_err = nullptr;
     size_t bytes = (size_t)(rows + 2 * ghost) * L->pitch;
@@ -481,6 +483,7 @@ int tsu_ising2d_destroy(tsu_ising2d* L) {
     if (L->d_sync) (void)hipFree(L->d_sync);
     if (L->d_xbuf) (void)hipFree(L->d_xbuf);
     if (L->d_batch) (void)hipFree(L->d_batch);
+    if (L->d_obs_batch) (void)hipFree(L->d_obs_batch);
     if (L->h_err) (void)hipHostFree(L->h_err);
     (void)hipEventDestroy(L->ev0);
     (void)hipEventDestroy(L->ev1);
@@ -603,7 +606,11 @@ int tsu_ising2d_sweep_part(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_t
     int use_tiled = !use_small && ((L->kernel == TSU_KERNEL_TILED) || (L->kernel == TSU_KERNEL_AUTO && tsu_ising2d_tiled_supported(L)));
     if (part != TSU_PART_ALL && !(use_tiled && tsu_ising2d_tiled_part_supported(L)))
         return tsu_fail(ctx, TSU_E_UNSUPPORTED, "ising2d_sweep_part: split sweeps need a slab on the tiled kernel with rows %% 64 == 0");
-    if (use_small) {
+    if (use_small && tsu_ising2d_planes_supported(L)) {
+        // colour planes in LDS, packed-byte update (ising2d_tiled.hip); k1_small below keeps the shapes it does not take
+        int rc = tsu_ising2d_planes_sweep(&L, 1, n_sweeps, &seed, &sweep0, &replica);
+        if (rc != TSU_OK) return rc;
+    } else if (use_small) {
         K1Params p = make_params(L, L->alloc[L->cur]);
         K1Table tbl;
         memcpy(tbl.t, L->table, sizeof(tbl.t));
@@ -782,6 +789,9 @@ int tsu_ising2d_sweep_batch(tsu_ising2d* const* lats, int n_lats, int n_sweeps, 
         }
         return rc;
     }
+    bool planes = true;
+    for (int i = 0; i < n_lats; ++i) planes = planes && tsu_ising2d_planes_supported(lats[i]) && lats[i]->periodic == lats[0]->periodic;
+    if (planes) return tsu_ising2d_planes_sweep(lats, n_lats, n_sweeps, seeds, sweep0s, replicas);
     std::vector<K1BatchItem> items((size_t)n_lats);
     for (int i = 0; i < n_lats; ++i) {
         tsu_ising2d* L = lats[i];
@@ -820,17 +830,27 @@ int tsu_ising2d_observables_batch(tsu_ising2d* const* lats, int n_lats, int64_t*
     tsu_ctx* ctx = lats[0]->ctx;
     TSU_REQUIRE(ctx, sum_s && sum_bonds, "ising2d_observables: NULL output");
     std::vector<int64_t> h((size_t)2 * n_lats);
+    // one accumulator array for the batch (with its first lattice): one memset, one launch per lattice, one copy back
+    tsu_ising2d* L0 = lats[0];
+    const size_t bytes = h.size() * sizeof(int64_t);
+    if (L0->obs_batch_cap < bytes) {
+        if (L0->d_obs_batch) (void)hipFree(L0->d_obs_batch);
+        L0->d_obs_batch = nullptr;
+        L0->obs_batch_cap = 0;
+        TSU_HIP_TRY(ctx, hipMalloc(&L0->d_obs_batch, bytes));
+        L0->obs_batch_cap = bytes;
+    }
+    TSU_HIP_TRY(ctx, hipMemsetAsync(L0->d_obs_batch, 0, bytes, ctx->stream));
     for (int i = 0; i < n_lats; ++i) {
         tsu_ising2d* L = lats[i];
         TSU_REQUIRE(ctx, L && L->ctx == ctx, "ising2d_observables_batch: lattice %d is NULL or belongs to another context", i);
         K1Params p = make_params(L, L->alloc[L->cur]);
-        TSU_HIP_TRY(ctx, hipMemsetAsync(L->d_obs, 0, 2 * sizeof(int64_t), ctx->stream));
         long long work = (long long)L->rows * ((L->cols + 15) / 16);
         unsigned blocks = (unsigned)((work + 255) / 256 < 512 ? (work + 255) / 256 : 512);  // one atomic pair per block: keep them few (14 ns each, serialised)
-        k4_observables<<<blocks, 256, 0, ctx->stream>>>(p, (long long*)L->d_obs);
-        TSU_HIP_TRY(ctx, hipMemcpyAsync(&h[(size_t)2 * i], L->d_obs, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        k4_observables<<<blocks, 256, 0, ctx->stream>>>(p, (long long*)L0->d_obs_batch + 2 * i);
     }
     TSU_HIP_TRY(ctx, hipGetLastError());
+    TSU_HIP_TRY(ctx, hipMemcpyAsync(h.data(), L0->d_obs_batch, bytes, hipMemcpyDeviceToHost, ctx->stream));
     TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < n_lats; ++i) {
         sum_s[i] = h[(size_t)2 * i];

@@ -16,6 +16,8 @@
 //   instruction; only an exact tie of the top 16 bits (2^-16 per site) evaluates the low half.
 #include "ising2d.h"
 
+#include <vector>
+
 typedef short v2s __attribute__((ext_vector_type(2)));
 typedef unsigned short v2us __attribute__((ext_vector_type(2)));
 
@@ -646,7 +648,7 @@ int pick_variant(const tsu_ising2d* L) {
         for (int ci = 0; whole && ci < (int)(sizeof(cand) / sizeof(cand[0])); ++ci) {
             const TileVariant& c = kVariants[cand[ci]];
             if (!(L->periodic ? c.kernel : c.open)) continue;
-            if (nch < c.WO + 2 || L->total_rows < c.H + 4 * KMAX) continue;
+            if (2 * nch < c.WO || L->total_rows < c.H + 4 * KMAX) continue;
             const long long nt = (long long)((L->rows + c.H - 1) / c.H) * ((nch + c.WO - 1) / c.WO);
             if (nt > cus) continue;
             const bool resident = (L->periodic ? c.resident : c.resident_open) && L->rows % c.H == 0 && nch % c.WO == 0;
@@ -658,10 +660,10 @@ int pick_variant(const tsu_ising2d* L) {
             }
         }
     }
-    // a variant must fit the lattice (tile not wider than the lattice; single wrap of the global row index) and, for an
-    // open lattice, have the OPEN form built; -1 = none does (generic kernel)
+    // a variant must fit the lattice (a tile is a window on the lattice's periodic extension: its octet and row indices
+    // wrap at most twice / once) and, for an open lattice, have the OPEN form built; -1 = none does (generic kernel)
     auto fits = [&](int vv) {
-        return ((L->cols + 15) / 16) >= kVariants[vv].WO + 2 && L->total_rows >= kVariants[vv].H + 4 * KMAX && (L->periodic || kVariants[vv].open);
+        return 2 * ((L->cols + 15) / 16) >= kVariants[vv].WO && L->total_rows >= kVariants[vv].H + 4 * KMAX && (L->periodic || kVariants[vv].open);
     };
     if (!fits(v)) {
         static const int fallback[] = {6, 26, 27};
@@ -681,7 +683,6 @@ int tsu_ising2d_tiled_supported(const tsu_ising2d* L) {
     if (pick_variant(L) < 0) return 0;                        // no tile shape fits (too narrow / too few rows): generic kernel
     const bool open_whole = !L->periodic && L->ghost == 0 && L->total_rows == L->rows;  // beyond its edges: nothing
     if (!L->wrap_rows && !open_whole && L->ghost < 2) return 0;
-    if (L->total_rows < kVariants[0].H + 4 * KMAX) return 0;  // single wrap of the global row index
     return 1;
 }
 
@@ -940,5 +941,198 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
         done += k;
     }
     TSU_HIP_TRY(ctx, hipGetLastError());
+    return TSU_OK;
+}
+
+// ================================================================== one-workgroup colour-plane kernel (small lattices)
+// A whole lattice of at most 1024 octets (32 x 32 ... 128 x 128: the reference's own sizes, BASELINE configs[0]) as two
+// colour planes of up-flags in one workgroup's LDS for all sweeps of a call: one thread per octet, the tiled kernel's
+// packed-byte update (one Philox block, 16-bit threshold compare, lazy low bits on ties) with true wrap-around
+// indices instead of a halo.  Same counters (octet, row, half-sweep), hence the same results as every other lattice
+// kernel.  Workgroup b of a launch sweeps lattice b of a batch (one temperature each of a scan).
+struct PlanesItem {
+    int8_t* buf;  // owned row 0 (updated in place: the lattice lives in LDS between the load and the store)
+    long long pitch;
+    int rows, cols, periodic;
+    uint32_t k0, k1, tag_hi, tag_lo, sweep0;
+    uint32_t tblH0, tblH1, tblL0, tblL1, t3H0, t3H1, t3L0, t3L1;
+    uint64_t thr[25];
+};
+
+template <bool OPEN>
+__global__ __launch_bounds__(1024) void k1_planes(const PlanesItem* __restrict__ items, PlanesItem one, int n_sweeps) {
+    __shared__ uint64_t s_planes[2 * 1024];
+    __shared__ uint64_t s_thr[25];
+    const PlanesItem& it = items ? items[blockIdx.x] : one;
+    const int tid = threadIdx.x;
+    const int rows = it.rows, cols = it.cols, nch = (cols + 15) >> 4, tasks = rows * nch;
+    if (tid < 25) s_thr[tid] = it.thr[tid];
+    const PhiloxKeys K = make_keys(it.k0, it.k1);
+    const bool active = tid < tasks;
+    const int r = active ? tid / nch : 0, q = active ? tid - r * nch : 0;
+    const int idx = r * nch + q;
+    uint64_t* const plane0 = s_planes;
+    uint64_t* const plane1 = s_planes + tasks;
+    // the columns of this chunk that exist (open lattices of ragged width: fewer in the last chunk)
+    int nv = cols - 16 * q;
+    if (nv > 16) nv = 16;
+    auto first_sites = [](int n) { return n >= 8 ? 0x0101010101010101ull : (((1ull << (8 * n)) - 1) & 0x0101010101010101ull); };
+    const uint64_t vm_e = first_sites((nv + 1) >> 1), vm_o = first_sites(nv >> 1);
+    int8_t* const chunk = it.buf + (long long)r * it.pitch + 16 * q;
+    if (active) {
+        const uint4 v = *reinterpret_cast<const uint4*>(chunk);
+        const uint32_t e0 = perm(v.y, v.x, 0x06040200u), e1 = perm(v.w, v.z, 0x06040200u);
+        const uint32_t o0 = perm(v.y, v.x, 0x07050301u), o1 = perm(v.w, v.z, 0x07050301u);
+        uint64_t ev = (uint64_t)(~(e0 >> 1) & 0x01010101u) | ((uint64_t)(~(e1 >> 1) & 0x01010101u) << 32);
+        uint64_t od = (uint64_t)(~(o0 >> 1) & 0x01010101u) | ((uint64_t)(~(o1 >> 1) & 0x01010101u) << 32);
+        ev &= vm_e;  // the row's pad bytes are 0, which would read as "up"
+        od &= vm_o;
+        ((r & 1) ? plane1 : plane0)[idx] = ev;  // the even columns of row r have colour r & 1
+        ((r & 1) ? plane0 : plane1)[idx] = od;
+    }
+    // neighbour octets: -1 = beyond an open edge (nothing there)
+    const int up = r > 0 ? idx - nch : (OPEN ? -1 : idx + (rows - 1) * nch);
+    const int dn = r < rows - 1 ? idx + nch : (OPEN ? -1 : idx - (rows - 1) * nch);
+    const int lf = q > 0 ? idx - 1 : (OPEN ? -1 : idx + nch - 1);
+    const int rt = q < nch - 1 ? idx + 1 : (OPEN ? -1 : idx - (nch - 1));
+    // a periodic lattice of ragged width wraps inside the last octet: the site after its last valid one (v_last - 1) is
+    // site 0 of octet 0, the site before site 0 of octet 0 is that last valid one
+    const int v_last = ((cols >> 1) & 7) ? ((cols >> 1) & 7) : 8;
+    const int shl = q == nch - 1 ? 8 * (v_last - 1) : 56, shr = q == 0 ? 8 * (v_last - 1) : 56;
+    Rows2Ctx c;
+    c.s_thr = s_thr;
+    c.t3H0 = it.t3H0; c.t3H1 = it.t3H1; c.t3L0 = it.t3L0; c.t3L1 = it.t3L1;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(c.tblH0) : "s"(it.tblH0));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(c.tblH1) : "s"(it.tblH1));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(c.tblL0) : "s"(it.tblL0));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(c.tblL1) : "s"(it.tblL1));
+    c.r_par = (uint32_t)(cols - 1) & 1u;
+    c.r_slot = ((uint32_t)(cols - 1) & 15u) >> 1;
+    c.rm_lo = c.r_slot < 4 ? 0xFFu << (8 * c.r_slot) : 0u;
+    c.rm_hi = c.r_slot < 4 ? 0u : 0xFFu << (8 * (c.r_slot - 4));
+    const bool row_edge = OPEN && (r == 0 || r == rows - 1);
+    const uint32_t tag_hi = it.tag_hi, tag_lo = it.tag_lo, k0 = it.k0, k1 = it.k1, sweep0 = it.sweep0;
+    for (int hsi = 0; hsi < 2 * n_sweeps; ++hsi) {
+        __syncthreads();
+        const int kappa = hsi & 1;
+        const uint32_t hs = 2u * (sweep0 + (uint32_t)(hsi >> 1)) + (uint32_t)kappa;
+        if (active) {
+            const uint64_t* Ps = kappa ? plane0 : plane1;
+            uint64_t* Pd = kappa ? plane1 : plane0;
+            const int par = (r + kappa) & 1;  // column parity of the sites updated in this row
+            const uint64_t U = (OPEN && up < 0) ? 0ull : Ps[up], D = (OPEN && dn < 0) ? 0ull : Ps[dn], C = Ps[idx];
+            // horizontal neighbours: compact bytes (j, j+1) when the parity is 1, (j-1, j) when it is 0
+            const int side = par ? rt : lf;
+            const uint64_t A = (OPEN && side < 0) ? 0ull : Ps[side];
+            const uint64_t S = par ? ((C >> 8) | ((A & 0xFFull) << shl)) : ((C << 8) | ((A >> shr) & 0xFFull));
+            const uint64_t cnt = U + D + C + S;  // bytes <= 4: no carries between sites
+            const uint32_t cnt_lo = (uint32_t)cnt, cnt_hi = (uint32_t)(cnt >> 32);
+            const u32x4 w = philox_vk((uint32_t)q, (uint32_t)r, hs, tag_hi, K);
+            u32x4 d;
+            uint32_t edge = 0;
+            if (OPEN) {
+                const bool l0 = !par && q == 0, r7 = q == nch - 1 && c.r_par == (uint32_t)par;
+                d = compare_octet_open(w, cnt_lo, cnt_hi, c, row_edge, l0, r7);
+                edge = (row_edge ? 1u : 0u) | (l0 ? 2u : 0u) | (r7 ? 4u : 0u) | (c.r_slot << 4);
+            } else {
+                d = compare_octet(w, cnt_lo, cnt_hi, c.tblH0, c.tblH1, c.tblL0, c.tblL1);
+            }
+            if (__builtin_expect(has_zero_field(d), 0)) d = resolve_ties(d, w, cnt_lo, cnt_hi, s_thr, (uint32_t)q, (uint32_t)r, hs, tag_lo, k0, k1, edge);
+            uint64_t n = pack_flags(d);
+            n &= par ? vm_o : vm_e;
+            Pd[idx] = n;
+        }
+    }
+    __syncthreads();
+    if (active) {
+        const uint64_t ev = ((r & 1) ? plane1 : plane0)[idx], od = ((r & 1) ? plane0 : plane1)[idx];
+        const uint32_t e0 = perm(0u, 0x000001FFu, (uint32_t)ev), e1 = perm(0u, 0x000001FFu, (uint32_t)(ev >> 32));
+        const uint32_t o0 = perm(0u, 0x000001FFu, (uint32_t)od), o1 = perm(0u, 0x000001FFu, (uint32_t)(od >> 32));
+        uint4 v = make_uint4(perm(o0, e0, 0x05010400u), perm(o0, e0, 0x07030602u), perm(o1, e1, 0x05010400u), perm(o1, e1, 0x07030602u));
+        if (nv < 16) {  // ragged last chunk: the pad bytes of the row stay 0
+            auto bytes = [](int n) { return n >= 4 ? 0xFFFFFFFFu : (n <= 0 ? 0u : (1u << (8 * n)) - 1u); };
+            v.x &= bytes(nv);
+            v.y &= bytes(nv - 4);
+            v.z &= bytes(nv - 8);
+            v.w &= bytes(nv - 12);
+        }
+        *reinterpret_cast<uint4*>(chunk) = v;
+    }
+}
+
+// whole lattices of at most 1024 octets, any width; an open lattice needs two rows and two columns (the packed compare
+// knows degrees 4, 3 and 2).  TSU_K1_PLANES=0: never (k1_small).
+int tsu_ising2d_planes_supported(const tsu_ising2d* L) {
+    static int enabled = -1;
+    if (enabled < 0) {
+        const char* e = getenv("TSU_K1_PLANES");
+        enabled = e ? atoi(e) : 1;
+    }
+    if (!enabled || L->ghost != 0 || L->total_rows != L->rows || L->row0 != 0) return 0;
+    if ((long long)L->rows * ((L->cols + 15) / 16) > 1024) return 0;
+    return L->rows >= 2 && L->cols >= 2;
+}
+
+// one launch for n lattices of one shape and boundary (workgroup b sweeps lattice b); caller checked planes_supported
+int tsu_ising2d_planes_sweep(tsu_ising2d* const* lats, int n, int n_sweeps, const uint64_t* seeds, const uint32_t* sweep0s,
+                             const uint32_t* replicas) {
+    tsu_ctx* ctx = lats[0]->ctx;
+    std::vector<PlanesItem> items((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const tsu_ising2d* L = lats[i];
+        PlanesItem& it = items[(size_t)i];
+        it.buf = L->alloc[L->cur] + (size_t)L->ghost * L->pitch;
+        it.pitch = (long long)L->pitch;
+        it.rows = L->rows;
+        it.cols = L->cols;
+        it.periodic = L->periodic;
+        it.k0 = (uint32_t)seeds[i];
+        it.k1 = (uint32_t)(seeds[i] >> 32);
+        it.tag_hi = TSU_TAG_ISING_HI | (replicas[i] << 8);
+        it.tag_lo = TSU_TAG_ISING_LO | (replicas[i] << 8);
+        it.sweep0 = sweep0s[i];
+        for (int c = 0; c < 25; ++c) it.thr[c] = L->table[c];
+        auto top16 = [](uint64_t thr) {
+            uint32_t thi = (uint32_t)(thr >> 16);
+            if (thi > 65535u) thi = 65535u;
+            return thi ^ 0x8000u;
+        };
+        uint32_t t16[5], t3[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int c = 0; c < 5; ++c) t16[c] = top16(L->table[4 * 5 + c]);
+        for (int c = 0; c < 4; ++c) t3[c] = top16(L->table[3 * 5 + c]);
+        for (int c = 0; c < 3; ++c) t3[4 + c] = top16(L->table[2 * 5 + c]);
+        it.t3L0 = (t3[0] & 0xFF) | ((t3[1] & 0xFF) << 8) | ((t3[2] & 0xFF) << 16) | ((t3[3] & 0xFF) << 24);
+        it.t3L1 = (t3[4] & 0xFF) | ((t3[5] & 0xFF) << 8) | ((t3[6] & 0xFF) << 16);
+        it.t3H0 = (t3[0] >> 8) | ((t3[1] >> 8) << 8) | ((t3[2] >> 8) << 16) | ((t3[3] >> 8) << 24);
+        it.t3H1 = (t3[4] >> 8) | ((t3[5] >> 8) << 8) | ((t3[6] >> 8) << 16);
+        it.tblL0 = (t16[0] & 0xFF) | ((t16[1] & 0xFF) << 8) | ((t16[2] & 0xFF) << 16) | ((t16[3] & 0xFF) << 24);
+        it.tblL1 = (t16[4] & 0xFF);
+        it.tblH0 = (t16[0] >> 8) | ((t16[1] >> 8) << 8) | ((t16[2] >> 8) << 16) | ((t16[3] >> 8) << 24);
+        it.tblH1 = (t16[4] >> 8);
+    }
+    const tsu_ising2d* L0c = lats[0];
+    const int tasks = L0c->rows * ((L0c->cols + 15) / 16);
+    const unsigned threads = (unsigned)((tasks + 63) / 64 * 64);
+    void (*const kern)(const PlanesItem*, PlanesItem, int) = L0c->periodic ? k1_planes<false> : k1_planes<true>;
+    if (n == 1) {
+        hipLaunchKernelGGL(kern, dim3(1), dim3(threads), 0, ctx->stream, (const PlanesItem*)nullptr, items[0], n_sweeps);
+    } else {
+        tsu_ising2d* L0 = lats[0];  // the staging buffer for the items lives with the first lattice of the batch
+        const size_t bytes = items.size() * sizeof(PlanesItem);
+        if (L0->batch_cap < bytes) {
+            if (L0->d_batch) (void)hipFree(L0->d_batch);
+            L0->d_batch = nullptr;
+            L0->batch_cap = 0;
+            TSU_HIP_TRY(ctx, hipMalloc(&L0->d_batch, bytes));
+            L0->batch_cap = bytes;
+        }
+        // stream order keeps a previous batch launch from still reading the buffer; the host array dies with this call,
+        // so the copy is waited for (a few KB); the launch itself stays asynchronous
+        TSU_HIP_TRY(ctx, hipMemcpyAsync(L0->d_batch, items.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+        TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(threads), 0, ctx->stream, (const PlanesItem*)L0->d_batch, items[0], n_sweeps);
+    }
+    TSU_HIP_TRY(ctx, hipGetLastError());
+    for (int i = 0; i < n; ++i) lats[i]->launches += 1;
     return TSU_OK;
 }
