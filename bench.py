@@ -315,6 +315,8 @@ def main():
             extra["ising2d_4096x8192"] = time_lattice(hip, ctx, 4096, 0, 240, cols=8192)
             for L2, k2 in ((8192, 5), (16384, 5)):
                 extra[f"ising2d_L{L2}"] = time_lattice(hip, ctx, L2, k2, 120)
+            # BASELINE configs[0], the reference's own CPU-runnable case (cpu_reference_order times its loop on the same lattice)
+            extra["ising2d_32x32"] = time_lattice(hip, ctx, 32, 0, 20000)
             extra["langevin_dim_2^20"] = time_langevin(hip, ctx)
             extra["dense_gibbs"] = time_dense(hip, ctx)
             out["extra"] = extra
