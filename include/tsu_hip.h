@@ -168,7 +168,7 @@ int tsu_dense_sweep(tsu_dense* d, double T, int n_sweeps, const int64_t* order, 
 /* The whole sampling run of GibbsSampler.sample_boltzmann (tsu/gibbs.py:196-213) from the resident state:
  * n_burnin sweeps, then n_samples x (n_sweeps sweeps, record the state).  samples_host receives n_samples*n bits.
  * order / replay_uniforms cover all (n_burnin + n_samples*n_sweeps) sweeps, row per sweep; sweep numbers for the
- * Philox stream count on from sweep0.  Systems of n <= 64 sites in natural order run as ONE launch of a single
+ * Philox stream count on from sweep0.  Systems of n <= 192 (fp32 J; 128 for fp64 J) sites in natural order run as ONE launch of a single
  * wave (the reference's published benchmark sizes: n = 1 and n = 10); larger ones loop tsu_dense_sweep on the device
  * side and copy the samples back once. */
 int tsu_dense_sample(tsu_dense* d, double T, int n_burnin, int n_sweeps, int n_samples, const int64_t* order,
@@ -176,13 +176,13 @@ int tsu_dense_sample(tsu_dense* d, double T, int n_burnin, int n_sweeps, int n_s
                      int8_t* samples_host);
 /* The loop of GibbsSampler.simulated_annealing (tsu/gibbs.py:366-391) from the resident state: step s does ONE sweep
  * at temperatures[s] and records the state; states_host receives n_steps*n bits (the caller evaluates the energies
- * and keeps the best, with the reference's own expression).  order / replay_uniforms: one row per step.  n <= 64 in
+ * and keeps the best, with the reference's own expression).  order / replay_uniforms: one row per step.  n <= 192 (fp32 J; 128 for fp64) in
  * natural order: one launch of a single wave for the whole schedule. */
 int tsu_dense_anneal(tsu_dense* d, const double* temperatures, int n_steps, const int64_t* order, uint64_t seed,
                      uint32_t sweep0, uint32_t replica, const double* replay_uniforms, int8_t* states_host);
 /* The replica loop of GibbsSampler.parallel_tempering (tsu/gibbs.py:300-306): replica r does n_sweeps sweeps of its own
  * state (states_host[r*n .. ], in and out) at temperatures[r] with its own seed / sweep counter / replica id;
- * replay_uniforms: NULL or n_replicas * n_sweeps * n doubles.  The handle's resident state is not used.  n <= 64: one
+ * replay_uniforms: NULL or n_replicas * n_sweeps * n doubles.  The handle's resident state is not used.  n <= 192 (fp32 J; 128 for fp64): one
  * launch, one wave per replica; larger systems are swept one replica after the other. */
 int tsu_dense_sweep_replicas(tsu_dense* d, int n_replicas, const double* temperatures, int n_sweeps, int8_t* states_host,
                              const uint64_t* seeds, const uint32_t* sweep0s, const uint32_t* replicas,

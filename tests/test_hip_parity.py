@@ -326,7 +326,7 @@ def test_ising2d_slab_decomposition_invariance(hip, periodic, nslab, ghost, k):
 
 
 # ----------------------------------------------------------------------------- K2 dense sweep
-@pytest.mark.parametrize("n", [1, 12, 64, 65, 200])
+@pytest.mark.parametrize("n", [1, 12, 64, 65, 100, 128, 129, 191, 192, 193, 200])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_dense_sweep_matches_oracle(hip, n, dtype):
     rng = np.random.default_rng(n)
@@ -352,6 +352,11 @@ def test_dense_sweep_matches_oracle(hip, n, dtype):
     d.sweep(T, 4, order=order, replay_uniforms=u)
     want = ora.c_dense_sweep_replay(st, J, b, T, u, order)
     np.testing.assert_array_equal(d.get_state().astype(np.int64), want)
+    # replayed uniforms, natural order (one wave up to 192 / 128 sites)
+    d.set_state(st)
+    d.sweep(T, 4, replay_uniforms=u)
+    np.testing.assert_array_equal(d.get_state().astype(np.int64), ora.c_dense_sweep_replay(st, J, b, T, u, None))
+    d.close()
 
 
 @pytest.mark.parametrize("n,dtype,T,sym", [(4500, "f32", 1.0, True), (2051, "f64", 0.3, False), (6144, "f32", 0.2, True)])
@@ -387,17 +392,20 @@ def test_dense_superblocks_match_oracle(hip, n, dtype, T, sym):
     d.close()
 
 
-@pytest.mark.parametrize("n", [1, 10, 64, 65, 200])
-def test_dense_sample_run_matches_oracle(hip, n):
-    """tsu_dense_sample (burn-in + n_samples x n_sweeps in one call; a single wave for n <= 64) against the oracle's
-    sweep-by-sweep chain: Philox uniforms, replayed uniforms, and (n > 64 path) a permuted order."""
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("n", [1, 10, 64, 65, 100, 128, 150, 192, 200])
+def test_dense_sample_run_matches_oracle(hip, n, dtype):
+    """tsu_dense_sample (burn-in + n_samples x n_sweeps in one call; a single wave up to 192 fp32 / 128 fp64 sites) against
+    the oracle's sweep-by-sweep chain: Philox uniforms, replayed uniforms in natural and (n > 64) permuted order."""
     rng = np.random.default_rng(100 + n)
     J = rng.normal(size=(n, n)) / max(1.0, np.sqrt(n))
     J = (J + J.T) / 2
+    if dtype == "f32":
+        J = J.astype(np.float32).astype(np.float64)
     b = rng.normal(size=n) * 0.4
     st = rng.integers(0, 2, size=n).astype(np.int8)
     T, burn, ns, m, seed = 0.8, 7, 3, 5, 31337
-    d = hip.DenseSystem(J, b)
+    d = hip.DenseSystem(J, b, hip.DTYPE_F64 if dtype == "f64" else hip.DTYPE_F32)
     d.set_state(st)
     got = d.sample(T, burn, ns, m, seed=seed, sweep0=11)
     cur = ora.dense_sweep_philox(st, J, b, T, burn, seed, sweep0=11)
@@ -407,18 +415,18 @@ def test_dense_sample_run_matches_oracle(hip, n):
     np.testing.assert_array_equal(d.get_state(), cur)  # the run leaves the last state resident
     total = burn + m * ns
     u = rng.random(size=(total, n))
-    order = np.array([rng.permutation(n) for _ in range(total)]) if n > 64 else None
-    d.set_state(st)
-    got = d.sample(T, burn, ns, m, order=order, replay_uniforms=u)
-    cur = ora.c_dense_sweep_replay(st, J, b, T, u[:burn], None if order is None else order[:burn])
-    for k in range(m):
-        lo = burn + k * ns
-        cur = ora.c_dense_sweep_replay(cur, J, b, T, u[lo:lo + ns], None if order is None else order[lo:lo + ns])
-        np.testing.assert_array_equal(got[k].astype(np.int64), cur)
+    for order in ([None, np.array([rng.permutation(n) for _ in range(total)])] if n > 64 else [None]):
+        d.set_state(st)
+        got = d.sample(T, burn, ns, m, order=order, replay_uniforms=u)
+        cur = ora.c_dense_sweep_replay(st, J, b, T, u[:burn], None if order is None else order[:burn])
+        for k in range(m):
+            lo = burn + k * ns
+            cur = ora.c_dense_sweep_replay(cur, J, b, T, u[lo:lo + ns], None if order is None else order[lo:lo + ns])
+            np.testing.assert_array_equal(got[k].astype(np.int64), cur)
     d.close()
 
 
-@pytest.mark.parametrize("n", [10, 64, 100])
+@pytest.mark.parametrize("n", [10, 64, 100, 128, 130])
 def test_dense_sweep_replicas_match_oracle(hip, n):
     """tsu_dense_sweep_replicas (a tempering ladder's replica loop in one call; one wave per replica for n <= 64):
     each replica == the oracle's chain at its temperature / seed / counter; replayed uniforms likewise."""

@@ -141,76 +141,164 @@ __global__ __launch_bounds__(256) void k2_block(const TJ* __restrict__ J, const 
 }
 
 // ================================================================== small systems: one wave, one launch per run
-// n <= 64 sites, natural order: the whole sample_boltzmann run (burn-in, then n_samples x n_sweeps sweeps with a
-// recorded state after each group) inside one wave.  Lane k owns site k; J sits in LDS as columns; every sweep
-// recomputes the fields from scratch (like the reference's np.dot per site) and resolves the sequential pass by jumping from flip to flip (ballot + ffs) as k2_block does.
-template <typename TJ>
-static __device__ __forceinline__ void k2_small_body(const TJ* __restrict__ J, const double* __restrict__ bias, int8_t* __restrict__ state,
-                                                     const double* __restrict__ uniforms, int8_t* __restrict__ samples, int n, double T,
-                                                     const double* __restrict__ temps, int n_burnin, int n_sweeps, int n_samples,
-                                                     uint32_t sweep0, uint32_t tag, uint32_t k0, uint32_t k1) {
-    __shared__ double col[DB][DB + 1];  // col[i][k] = J[k][i]
+// n <= 64 M sites (M = 1..3 register slots per lane), natural order: the whole sample_boltzmann run (burn-in, then
+// n_samples x n_sweeps sweeps with a recorded state after each group) inside ONE wave.  Lane k owns sites k, 64 + k,
+// 128 + k; J sits in LDS as columns (fp32 J: up to 192 sites = 148 KB, fp64: up to 128); every sweep recomputes the
+// fields from scratch (like the reference's np.dot per site) and resolves the sequential pass slot after slot by a
+// fixed-point iteration over the slot's 64 sites.  No barrier, no launch and no global memory access inside a sweep.
+#define K2W_MAX_SLOTS 3
+// u < sigmoid(x) <=> x > logit(u): a float32 logit is computed once per site and sweep, outside the flip-to-flip
+// chain, so a decision inside the chain is one multiply, a conversion and a few float compares.  The float quantities
+// carry errors below 1e-5 (1 + |logit|); whenever x is within 1e-4 (1 + |logit|) of the logit, or within 1e-3 of the
+// +-20 clamp, the reference's float64 expression (gibbs.py:73-77,126) decides, so outcomes are its own.
+static __device__ __forceinline__ float k2w_logit(double u) {
+    return __logf((float)u) - __logf((float)(1.0 - u));  // 1 - u in float64: no cancellation for u near 1
+}
+static __device__ __forceinline__ int k2w_decide(double fk, double u, float lg, double T, double invT) {
+    const float xf = (float)(fk * invT);
+    if (fabsf(fabsf(xf) - 20.0f) < 1e-3f || !(fabsf(xf - lg) > 1e-4f * (1.0f + fabsf(lg)))) return (u < sigmoid_clamped(fk / T)) ? 1 : 0;
+    if (xf > 20.0f) return 1;
+    if (xf < -20.0f) return 0;
+    return xf > lg ? 1 : 0;
+}
+
+template <typename TJ, int M>
+static __device__ __forceinline__ void k2_wave_body(const TJ* __restrict__ J, const double* __restrict__ bias, int8_t* __restrict__ state,
+                                                    const double* __restrict__ uniforms, int8_t* __restrict__ samples, int n, double T,
+                                                    const double* __restrict__ temps, int n_burnin, int n_sweeps, int n_samples,
+                                                    uint32_t sweep0, uint32_t tag, uint32_t k0, uint32_t k1) {
+    extern __shared__ unsigned char k2w_lds[];
+    constexpr int STRIDE = 64 * M + 1;  // col[i * STRIDE + k] = J[k][i]; odd stride: the transposing stores do not conflict
+    TJ* col = reinterpret_cast<TJ*>(k2w_lds);
     const int lane = threadIdx.x;
-    const bool on = lane < n;
-    for (int i = 0; i < n; ++i) col[i][lane] = on ? (double)J[(size_t)lane * n + i] : 0.0;
+    for (int k = 0; k < n; ++k) {  // row k of J, read coalesced, stored as column entries
+#pragma unroll
+        for (int t = 0; t < M; ++t) {
+            const int i = t * 64 + lane;
+            if (i < n) col[i * STRIDE + k] = J[(size_t)k * n + i];
+        }
+    }
+    for (int k = n; k < 64 * ((n + 63) / 64); ++k) {  // entries the idle lanes of the last slot read
+#pragma unroll
+        for (int t = 0; t < M; ++t) {
+            const int i = t * 64 + lane;
+            if (i < n) col[i * STRIDE + k] = (TJ)0;
+        }
+    }
     __syncthreads();
-    const double bk = (on && bias) ? bias[lane] : 0.0;
-    double invT = 1.0 / T;  // or one temperature per sweep (an annealing schedule)
-    int bit = on ? state[lane] : 0;
+    bool on[M];
+    double bk[M], fk[M], u[M], u_next[M];
+    int bit[M];
     const int total = n_burnin + n_samples * n_sweeps;
+#pragma unroll
+    for (int t = 0; t < M; ++t) {
+        const int site = t * 64 + lane;
+        on[t] = site < n;
+        bk[t] = (on[t] && bias) ? bias[site] : 0.0;
+        bit[t] = on[t] ? state[site] : 0;
+        u_next[t] = (on[t] && uniforms && total > 0) ? uniforms[site] : 2.0;
+    }
+    double invT = 1.0 / T;  // or one temperature per sweep (an annealing schedule)
     int next_record = n_burnin + n_sweeps - 1, rec = 0;
-    double u_next = (on && uniforms && total > 0) ? uniforms[lane] : 2.0;
     for (int sw = 0; sw < total; ++sw) {
         if (temps) {
             T = temps[sw];
             invT = 1.0 / T;
         }
-        double u = 2.0;
-        if (on) u = uniforms ? u_next : dense_uniform((uint32_t)lane, sweep0 + (uint32_t)sw, tag, k0, k1);
-        if (on && uniforms && sw + 1 < total) u_next = uniforms[(size_t)(sw + 1) * n + lane];  // in flight during this sweep
-        const unsigned long long up = __ballot(bit != 0);
-        double fk = bk;
-        for (int i = 0; i < n; ++i) {  // ascending i, all LDS reads independent of the adds
-            const double c = col[i][lane];
-            if ((up >> i) & 1ull) fk += c;
+        unsigned long long up[M];
+#pragma unroll
+        for (int t = 0; t < M; ++t) {
+            const int site = t * 64 + lane;
+            u[t] = 0.5;  // idle lanes: any value with a finite logit (they never take part in a ballot)
+            if (on[t]) u[t] = uniforms ? u_next[t] : dense_uniform((uint32_t)site, sweep0 + (uint32_t)sw, tag, k0, k1);
+            if (on[t] && uniforms && sw + 1 < total) u_next[t] = uniforms[(size_t)(sw + 1) * n + site];  // in flight during this sweep
+            up[t] = __ballot(bit[t] != 0);
+            fk[t] = bk[t];
         }
-        // u < sigmoid(x): a float32 sigmoid settles it unless u is within 1e-5 of it (or x within 1e-3 of the +-20
-        // clamp); those rare cases take the reference's float64 expression (gibbs.py:73-77,126), so outcomes are its
-        const float uf = (float)u;
-        int cursor = 0;
-        while (true) {
-            const float xf = (float)(fk * invT);
-            int cand;
-            if (fabsf(fabsf(xf) - 20.0f) < 1e-3f) cand = (u < sigmoid_clamped(fk / T)) ? 1 : 0;
-            else if (xf > 20.0f) cand = 1;
-            else if (xf < -20.0f) cand = 0;
-            else {
-                const float du = uf - 1.0f / (1.0f + __expf(-xf));
-                cand = fabsf(du) <= 1e-5f ? ((u < sigmoid_clamped(fk / T)) ? 1 : 0) : (du < 0.0f ? 1 : 0);
+#pragma unroll
+        for (int tt = 0; tt < M; ++tt) {
+            const int cnt = n - tt * 64 < 64 ? n - tt * 64 : 64;
+            // ascending site index; branch-free (a site that is down adds +0.0) so that the LDS reads of several sites are in
+            // flight together instead of one read latency per site
+#pragma unroll 8
+            for (int ii = 0; ii < cnt; ++ii) {
+                const double b = ((up[tt] >> ii) & 1ull) ? 1.0 : 0.0;
+                const TJ* c = col + (tt * 64 + ii) * STRIDE + lane;
+#pragma unroll
+                for (int t = 0; t < M; ++t) fk[t] += b * (double)c[t * 64];
             }
-            const unsigned long long want = __ballot(on && lane >= cursor && cand != bit);
-            if (want == 0ull) break;
-            const int i = __ffsll((long long)want) - 1;
-            const int delta = __shfl(cand - bit, i, 64);
-            if (lane == i) bit = cand;
-            fk += (double)delta * col[i][lane];
-            cursor = i + 1;
+        }
+#pragma unroll
+        for (int s = 0; s < M; ++s) {
+            // The sequential pass over the 64 sites of slot s is the unique solution of a triangular system: delta_k =
+            // decide(f_k + sum_{j<k} J_kj delta_j) - bit_k.  It is solved by fixed-point iteration with all lanes
+            // deciding at once: lane k is exact from iteration k on, in practice a handful of iterations suffice, and the
+            // column reads of an iteration's changes are in flight together instead of one LDS latency per flip.
+            const float lg = k2w_logit(u[s]);
+            int d_prev = 0;     // this lane's current candidate flip (new bit - old bit)
+            double corr = 0.0;  // sum over the earlier lanes' candidate flips of delta_j J[k][j]
+            for (int iter = 0; iter < 66 && s * 64 < n; ++iter) {
+                const int d_new = on[s] ? k2w_decide(fk[s] + corr, u[s], lg, T, invT) - bit[s] : 0;
+                unsigned long long chg = __ballot(d_new != d_prev);
+                if (chg == 0ull) break;
+                const int diff = d_new - d_prev;
+                d_prev = d_new;
+                while (chg) {  // four changed sites per round: their column entries are read together
+                    int j[4], dd[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        j[q] = chg ? __ffsll((long long)chg) - 1 : 0;
+                        dd[q] = chg ? __builtin_amdgcn_readlane(diff, j[q]) : 0;
+                        chg &= chg - 1ull;
+                    }
+                    TJ c[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) c[q] = col[(s * 64 + j[q]) * STRIDE + s * 64 + lane];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) corr += (lane > j[q]) ? (double)dd[q] * (double)c[q] : 0.0;
+                }
+            }
+            bit[s] += d_prev;
+            if (s + 1 < M && (s + 1) * 64 < n) {  // the later slots see every flip of this one
+                unsigned long long flips = __ballot(d_prev != 0);
+                while (flips) {
+                    int j[4], dd[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        j[q] = flips ? __ffsll((long long)flips) - 1 : 0;
+                        dd[q] = flips ? __builtin_amdgcn_readlane(d_prev, j[q]) : 0;
+                        flips &= flips - 1ull;
+                    }
+#pragma unroll
+                    for (int t = s + 1; t < M; ++t) {
+                        TJ c[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) c[q] = col[(s * 64 + j[q]) * STRIDE + t * 64 + lane];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) fk[t] += (double)dd[q] * (double)c[q];
+                    }
+                }
+            }
         }
         if (sw == next_record) {
-            if (on) samples[(size_t)rec * n + lane] = (int8_t)bit;
+#pragma unroll
+            for (int t = 0; t < M; ++t)
+                if (on[t]) samples[(size_t)rec * n + t * 64 + lane] = (int8_t)bit[t];
             ++rec;
             next_record += n_sweeps;
         }
     }
-    if (on) state[lane] = (int8_t)bit;
+#pragma unroll
+    for (int t = 0; t < M; ++t)
+        if (on[t]) state[t * 64 + lane] = (int8_t)bit[t];
 }
 
-template <typename TJ>
+template <typename TJ, int M>
 __global__ __launch_bounds__(64) void k2_small(const TJ* __restrict__ J, const double* __restrict__ bias, int8_t* __restrict__ state,
                                               const double* __restrict__ uniforms, int8_t* __restrict__ samples, int n, double T,
                                               const double* __restrict__ temps, int n_burnin, int n_sweeps, int n_samples,
                                               uint32_t sweep0, uint32_t tag, uint32_t k0, uint32_t k1) {
-    k2_small_body<TJ>(J, bias, state, uniforms, samples, n, T, temps, n_burnin, n_sweeps, n_samples, sweep0, tag, k0, k1);
+    k2_wave_body<TJ, M>(J, bias, state, uniforms, samples, n, T, temps, n_burnin, n_sweeps, n_samples, sweep0, tag, k0, k1);
 }
 
 // the replicas of a tempering ladder: block r sweeps state r at its own temperature with its own stream
@@ -219,13 +307,71 @@ struct K2Replica {
     uint32_t sweep0, tag, k0, k1;
 };
 
-template <typename TJ>
+template <typename TJ, int M>
 __global__ __launch_bounds__(64) void k2_small_replicas(const TJ* __restrict__ J, const double* __restrict__ bias, int8_t* __restrict__ states,
                                                        const double* __restrict__ uniforms, const K2Replica* __restrict__ reps, int n,
                                                        int n_sweeps) {
     const K2Replica rp = reps[blockIdx.x];
-    k2_small_body<TJ>(J, bias, states + (size_t)blockIdx.x * n, uniforms ? uniforms + (size_t)blockIdx.x * n_sweeps * n : nullptr, nullptr, n,
-                      rp.T, nullptr, n_sweeps, 1, 0, rp.sweep0, rp.tag, rp.k0, rp.k1);
+    k2_wave_body<TJ, M>(J, bias, states + (size_t)blockIdx.x * n, uniforms ? uniforms + (size_t)blockIdx.x * n_sweeps * n : nullptr, nullptr, n,
+                        rp.T, nullptr, n_sweeps, 1, 0, rp.sweep0, rp.tag, rp.k0, rp.k1);
+}
+
+// slots per lane the one-wave kernels need for this system, 0 if it does not fit one CU's LDS (TSU_K2_WAVE=0: at most 1)
+static int k2w_slots(const tsu_dense* d) {
+    static int enabled = -1;
+    if (enabled < 0) {
+        const char* e = getenv("TSU_K2_WAVE");
+        enabled = e ? atoi(e) : 1;
+    }
+    const int m = (d->n + 63) / 64;
+    const int cap = !enabled ? 1 : (d->dtype == TSU_DTYPE_F64 ? 2 : K2W_MAX_SLOTS);
+    return m <= cap ? m : 0;
+}
+
+static size_t k2w_lds_bytes(const tsu_dense* d, int m) {
+    return (size_t)d->n * (size_t)(64 * m + 1) * (d->dtype == TSU_DTYPE_F64 ? 8 : 4);
+}
+
+typedef void (*k2w_run_fn)(const void*, const double*, int8_t*, const double*, int8_t*, int, double, const double*, int, int, int, uint32_t,
+                           uint32_t, uint32_t, uint32_t);
+typedef void (*k2w_rep_fn)(const void*, const double*, int8_t*, const double*, const K2Replica*, int, int);
+
+// one launch of the one-wave kernel (grid 1) for a system k2w_slots accepts
+static hipError_t k2w_launch(const tsu_dense* d, int m, hipStream_t stream, const double* uniforms, int8_t* samples, double T,
+                             const double* temps, int n_burnin, int n_sweeps, int n_samples, uint32_t sweep0, uint32_t tag, uint32_t k0,
+                             uint32_t k1) {
+    static const k2w_run_fn table[2][K2W_MAX_SLOTS] = {
+        {(k2w_run_fn)k2_small<float, 1>, (k2w_run_fn)k2_small<float, 2>, (k2w_run_fn)k2_small<float, 3>},
+        {(k2w_run_fn)k2_small<double, 1>, (k2w_run_fn)k2_small<double, 2>, nullptr}};
+    static bool attr[2][K2W_MAX_SLOTS] = {};
+    const int ti = d->dtype == TSU_DTYPE_F64 ? 1 : 0;
+    const k2w_run_fn fn = table[ti][m - 1];
+    if (!attr[ti][m - 1]) {
+        hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr[ti][m - 1] = true;
+    }
+    hipLaunchKernelGGL(fn, dim3(1), dim3(64), k2w_lds_bytes(d, m), stream, (const void*)d->J, (const double*)d->bias, d->state, uniforms, samples,
+                       d->n, T, temps, n_burnin, n_sweeps, n_samples, sweep0, tag, k0, k1);
+    return hipGetLastError();
+}
+
+static hipError_t k2w_launch_replicas(const tsu_dense* d, int m, hipStream_t stream, int n_replicas, int8_t* states, const double* uniforms,
+                                      const K2Replica* reps, int n_sweeps) {
+    static const k2w_rep_fn table[2][K2W_MAX_SLOTS] = {
+        {(k2w_rep_fn)k2_small_replicas<float, 1>, (k2w_rep_fn)k2_small_replicas<float, 2>, (k2w_rep_fn)k2_small_replicas<float, 3>},
+        {(k2w_rep_fn)k2_small_replicas<double, 1>, (k2w_rep_fn)k2_small_replicas<double, 2>, nullptr}};
+    static bool attr[2][K2W_MAX_SLOTS] = {};
+    const int ti = d->dtype == TSU_DTYPE_F64 ? 1 : 0;
+    const k2w_rep_fn fn = table[ti][m - 1];
+    if (!attr[ti][m - 1]) {
+        hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr[ti][m - 1] = true;
+    }
+    hipLaunchKernelGGL(fn, dim3((unsigned)n_replicas), dim3(64), k2w_lds_bytes(d, m), stream, (const void*)d->J, (const double*)d->bias, states,
+                       uniforms, reps, d->n, n_sweeps);
+    return hipGetLastError();
 }
 
 __global__ __launch_bounds__(256) void k2_energy(const double* __restrict__ f, const int8_t* __restrict__ s,
@@ -589,6 +735,15 @@ int tsu_dense_sweep(tsu_dense* d, double T, int n_sweeps, const int64_t* order, 
         TSU_HIP_TRY(ctx, hipMemcpyAsync(d->uniforms, replay_uniforms, cnt * 8, hipMemcpyHostToDevice, ctx->stream));
     }
     if (order || replay_uniforms) TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host buffers are the caller's
+    if (!order) {
+        // systems of at most 192 (fp32) / 128 (fp64) sites: all sweeps of the call in one launch of a single wave
+        const int wave_m = k2w_slots(d);
+        if (wave_m) {
+            TSU_HIP_TRY(ctx, k2w_launch(d, wave_m, ctx->stream, replay_uniforms ? d->uniforms : nullptr, nullptr, T, nullptr, n_sweeps, 1, 0, sweep0,
+                                        TSU_TAG_DENSE | (replica << 8), (uint32_t)seed, (uint32_t)(seed >> 32)));
+            return TSU_OK;
+        }
+    }
     static int use_sb = -1, use_coop = -1;
     if (use_sb < 0) {
         const char* e = getenv("TSU_K2_SUPERBLOCK");
@@ -650,7 +805,8 @@ static int dense_run(tsu_dense* d, double T, const double* temps, int n_burnin, 
         TSU_HIP_TRY(ctx, hipMalloc(&d->samples, out_bytes));
         d->samples_cap = out_bytes;
     }
-    if (n <= DB && !order) {
+    const int wave_m = order ? 0 : k2w_slots(d);
+    if (wave_m) {
         const double* temps_dev = nullptr;
         if (temps && total > 0) {
             if (d->temps_cap < (size_t)total) {
@@ -676,17 +832,9 @@ static int dense_run(tsu_dense* d, double T, const double* temps, int n_burnin, 
             TSU_HIP_TRY(ctx, hipMemcpyAsync(d->uniforms, replay_uniforms, cnt * 8, hipMemcpyHostToDevice, ctx->stream));
         }
         const uint32_t tag = TSU_TAG_DENSE | (replica << 8);
-        if (total > 0) {
-            if (d->dtype == TSU_DTYPE_F64)
-                k2_small<double><<<1, 64, 0, ctx->stream>>>((const double*)d->J, d->bias, d->state, replay_uniforms ? d->uniforms : nullptr,
-                                                            d->samples, n, T, temps_dev, n_burnin, n_sweeps, n_samples, sweep0, tag,
-                                                            (uint32_t)seed, (uint32_t)(seed >> 32));
-            else
-                k2_small<float><<<1, 64, 0, ctx->stream>>>((const float*)d->J, d->bias, d->state, replay_uniforms ? d->uniforms : nullptr,
-                                                           d->samples, n, T, temps_dev, n_burnin, n_sweeps, n_samples, sweep0, tag,
-                                                           (uint32_t)seed, (uint32_t)(seed >> 32));
-            TSU_HIP_TRY(ctx, hipGetLastError());
-        }
+        if (total > 0)
+            TSU_HIP_TRY(ctx, k2w_launch(d, wave_m, ctx->stream, replay_uniforms ? d->uniforms : nullptr, d->samples, T, temps_dev, n_burnin, n_sweeps,
+                                        n_samples, sweep0, tag, (uint32_t)seed, (uint32_t)(seed >> 32)));
     } else {
         // larger systems: the sweep paths above, one call per recorded state; samples gathered on the device
         // (with a schedule every recorded state is one sweep: n_burnin == 0 and n_sweeps == 1)
@@ -736,7 +884,8 @@ int tsu_dense_sweep_replicas(tsu_dense* d, int n_replicas, const double* tempera
             TSU_REQUIRE(ctx, states_host[(size_t)r * n + i] == 0 || states_host[(size_t)r * n + i] == 1, "dense_set_state: state must be 0/1");
     }
     if (n_sweeps == 0) return TSU_OK;
-    if (n > DB) {  // larger systems: one replica after the other through the sweep paths
+    const int wave_m = k2w_slots(d);
+    if (!wave_m) {  // larger systems: one replica after the other through the sweep paths
         for (int r = 0; r < n_replicas; ++r) {
             int rc = tsu_dense_set_state(d, states_host + (size_t)r * n);
             if (rc == TSU_OK)
@@ -771,11 +920,7 @@ int tsu_dense_sweep_replicas(tsu_dense* d, int n_replicas, const double* tempera
     TSU_HIP_TRY(ctx, hipMemcpyAsync(d_states, states_host, sbytes, hipMemcpyHostToDevice, ctx->stream));
     if (ubytes) TSU_HIP_TRY(ctx, hipMemcpyAsync(d_uni, replay_uniforms, ubytes, hipMemcpyHostToDevice, ctx->stream));
     TSU_HIP_TRY(ctx, hipMemcpyAsync(d_reps, reps.data(), rbytes, hipMemcpyHostToDevice, ctx->stream));
-    if (d->dtype == TSU_DTYPE_F64)
-        k2_small_replicas<double><<<(unsigned)n_replicas, 64, 0, ctx->stream>>>((const double*)d->J, d->bias, d_states, d_uni, d_reps, n, n_sweeps);
-    else
-        k2_small_replicas<float><<<(unsigned)n_replicas, 64, 0, ctx->stream>>>((const float*)d->J, d->bias, d_states, d_uni, d_reps, n, n_sweeps);
-    TSU_HIP_TRY(ctx, hipGetLastError());
+    TSU_HIP_TRY(ctx, k2w_launch_replicas(d, wave_m, ctx->stream, n_replicas, d_states, d_uni, d_reps, n_sweeps));
     TSU_HIP_TRY(ctx, hipMemcpyAsync(states_host, d_states, sbytes, hipMemcpyDeviceToHost, ctx->stream));
     TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TSU_OK;
