@@ -1,7 +1,7 @@
 """Randomized checks of the Langevin kernel, the one-workgroup lattice kernel and the lattice batch call (development aid)."""
 import os, sys, random
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tsu-emulator_amd"))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tsu-emulator_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 from tsu import _hip
 from oracle import oracle as ora

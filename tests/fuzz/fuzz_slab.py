@@ -1,6 +1,6 @@
 """Randomized check: a slab that is its own neighbour (world size 1, device halo copies) == the plain periodic lattice."""
 import os, sys, zlib, random
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tsu-emulator_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tsu-emulator_amd"))
 import torch
 from tsu import _hip
 from tsu.distributed import SlabLattice

@@ -1,6 +1,6 @@
 """One-off randomized cross-check of the one-workgroup colour-plane kernel against the generic kernel (development aid)."""
 import os, sys, zlib, random
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tsu-emulator_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tsu-emulator_amd"))
 import numpy as np
 from tsu import _hip
 random.seed(int(os.environ.get("FUZZ_SEED", "1")))
