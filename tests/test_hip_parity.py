@@ -326,7 +326,7 @@ def test_ising2d_slab_decomposition_invariance(hip, periodic, nslab, ghost, k):
 
 
 # ----------------------------------------------------------------------------- K2 dense sweep
-@pytest.mark.parametrize("n", [1, 12, 64, 65, 100, 128, 129, 191, 192, 193, 200])
+@pytest.mark.parametrize("n", [1, 12, 64, 65, 100, 128, 129, 191, 192, 193, 200, 333, 448, 449, 512, 576, 577])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_dense_sweep_matches_oracle(hip, n, dtype):
     rng = np.random.default_rng(n)

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np
 from tsu import _hip as hip
 ctx = hip.Context.default()
-for n in (65, 96, 128, 256, 512, 1024, 2048, 4096, 8192):
+for n in [int(v) for v in os.environ.get("SIZES", "65,96,128,256,512,1024,2048,4096,8192").split(",")]:
     rng = np.random.default_rng(n)
     G = rng.standard_normal((n, n)).astype(np.float32)
     J = ((G + G.T) / 2 / np.sqrt(n)).astype(np.float32)

@@ -374,6 +374,144 @@ static hipError_t k2w_launch_replicas(const tsu_dense* d, int m, hipStream_t str
     return hipGetLastError();
 }
 
+// ================================================================== mid-size systems: one workgroup, one launch per call
+// 192 (128) < n <= 1024, natural order: thread i owns site i (field, logit, correction, bit in registers), J^T is read
+// from global memory (L2-resident: 4 MB at n = 1024) one COLUMN per changed site -- coalesced across the threads, no
+// reductions.  A sweep is the fixed point delta = decide(f + L delta) - s over the whole system as one block (site k is
+// exact from iteration k on; about a dozen iterations in practice): every iteration lists the sites whose decision
+// changed (ascending, so floating-point sums do not depend on timing) and every thread adds their column entries with
+// j < i to its correction.  The flips are then added to every field (fields are handed from sweep to sweep and
+// recomputed from scratch every K2WG_REFRESH sweeps).  An iteration costs three workgroup barriers instead of a grid
+// barrier: n = 256 14 us per sweep against 43 us on the grid-wide path, n = 448 27 us against 46 us.
+#define K2WG_MAX_N 1024
+#define K2WG_REFRESH 64
+
+struct K2wgList {
+    int j[K2WG_MAX_N + 64];  // padded with (site 0, value 0) up to the next multiple of 64 entries
+    int d[K2WG_MAX_N + 64];
+    int wcount[16];
+};
+
+// every thread calls it; sites with pred set are listed in ascending order with their value; returns the list length
+static __device__ __forceinline__ int k2wg_build(K2wgList& L, bool pred, int value, int site, int wave, int lane, int nwaves) {
+    const unsigned long long b = __ballot(pred);
+    if (lane == 0) L.wcount[wave] = __popcll(b);
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int w = 0; w < nwaves; ++w) {
+        const int c = L.wcount[w];
+        before += w < wave ? c : 0;
+        total += c;
+    }
+    if (pred) {
+        const int at = before + __popcll(b & ((1ull << lane) - 1ull));
+        L.j[at] = site;
+        L.d[at] = value;
+    }
+    if (threadIdx.x < 64) {  // padding: the readers take whole groups of 64 entries
+        L.j[total + threadIdx.x] = 0;
+        L.d[total + threadIdx.x] = 0;
+    }
+    __syncthreads();
+    return total;
+}
+
+// one entry of J^T through a buffer descriptor: scalar row offset (the listed site) + one per-lane column offset for
+// every load of a batch, so a load in flight holds nothing but its result register
+typedef unsigned int k2wg_v2u __attribute__((ext_vector_type(2)));
+template <typename TJ>
+struct K2wgLoad;
+template <>
+struct K2wgLoad<float> {
+    static __device__ __forceinline__ float ld(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    }
+};
+template <>
+struct K2wgLoad<double> {
+    static __device__ __forceinline__ double ld(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+    }
+};
+
+// acc += sum over the listed sites j (only j < i when TRI) of d_j * JT[j][i], ascending j.  Lane l of every wave picks up
+// entry e0 + l of the (padded) list with one LDS read per 64 entries; the entries then reach the scalar unit by
+// v_readlane, and a batch of 32 column loads is in flight per thread (the loop is bound by the L2 round trip).
+template <typename TJ, bool TRI>
+static __device__ __forceinline__ double k2wg_apply(__amdgpu_buffer_rsrc_t JT, const K2wgList& L, int cnt, int n, int i, int lane, bool on,
+                                                    double acc) {
+    constexpr int B = 32;
+    const int voff = (on ? i : 0) * (int)sizeof(TJ);  // idle threads read a valid entry and never use it
+    const int row_bytes = n * (int)sizeof(TJ);
+    for (int e0 = 0; e0 < cnt; e0 += 64) {
+        const int my_j = L.j[e0 + lane], my_d = L.d[e0 + lane];
+#pragma unroll
+        for (int h = 0; h < 64; h += B) {
+            if (e0 + h >= cnt) break;
+            TJ x[B];
+#pragma unroll
+            for (int g = 0; g < B; g += 8) {  // groups of eight: a short list (most iterations) issues few loads
+                if (e0 + h + g < cnt) {
+#pragma unroll
+                    for (int q = g; q < g + 8; ++q) x[q] = K2wgLoad<TJ>::ld(JT, voff, __builtin_amdgcn_readlane(my_j, h + q) * row_bytes);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < B; g += 8) {
+                if (e0 + h + g < cnt) {
+#pragma unroll
+                    for (int q = g; q < g + 8; ++q) {
+                        const int j = __builtin_amdgcn_readlane(my_j, h + q), dd = __builtin_amdgcn_readlane(my_d, h + q);
+                        acc += (!TRI || j < i) ? (double)dd * (double)x[q] : 0.0;
+                    }
+                }
+            }
+        }
+    }
+    return acc;
+}
+
+template <typename TJ>
+__global__ __launch_bounds__(1024) void k2_wg(const TJ* __restrict__ JTp, const double* __restrict__ bias, int8_t* __restrict__ state,
+                                             const double* __restrict__ uniforms, int n, double T, int n_sweeps, uint32_t sweep0,
+                                             uint32_t tag, uint32_t k0, uint32_t k1, unsigned* __restrict__ info) {
+    __shared__ K2wgList L;
+    const __amdgpu_buffer_rsrc_t JT = __builtin_amdgcn_make_buffer_rsrc(const_cast<TJ*>(JTp), 0, n * n * (int)sizeof(TJ), 0x00020000);
+    const int i = threadIdx.x, lane = i & 63, wave = i >> 6, nwaves = blockDim.x >> 6;
+    const bool on = i < n;
+    const double invT = 1.0 / T, b = (on && bias) ? bias[i] : 0.0;
+    int bit = on ? state[i] : 0;
+    double f = 0.0;
+    int worst = 0;
+    for (int sw = 0; sw < n_sweeps; ++sw) {
+        if (sw % K2WG_REFRESH == 0) {  // fields from scratch: b + sum over the sites that are up of their column
+            const int cnt = k2wg_build(L, on && bit != 0, 1, i, wave, lane, nwaves);
+            f = k2wg_apply<TJ, false>(JT, L, cnt, n, i, lane, on, b);
+        }
+        double u = 0.5;
+        if (on) u = uniforms ? uniforms[(size_t)sw * n + i] : dense_uniform((uint32_t)i, sweep0 + (uint32_t)sw, tag, k0, k1);
+        const float lg = k2w_logit(u);
+        int d_prev = 0;
+        double corr = 0.0;
+        int iter = 0;
+        for (; iter < n + 2; ++iter) {
+            const int d_new = on ? k2w_decide(f + corr, u, lg, T, invT) - bit : 0;
+            const int cnt = k2wg_build(L, d_new != d_prev, d_new - d_prev, i, wave, lane, nwaves);
+            if (cnt == 0) break;
+            d_prev = d_new;
+            corr = k2wg_apply<TJ, true>(JT, L, cnt, n, i, lane, on, corr);
+        }
+        if (iter > worst) worst = iter;
+        bit += d_prev;
+        if (sw + 1 < n_sweeps && (sw + 1) % K2WG_REFRESH != 0) {  // hand the fields on: every flip, every row
+            const int cnt = k2wg_build(L, d_prev != 0, d_prev, i, wave, lane, nwaves);
+            f = k2wg_apply<TJ, false>(JT, L, cnt, n, i, lane, on, f);
+        }
+    }
+    if (on) state[i] = (int8_t)bit;
+    if (i == 0 && info) info[0] = (unsigned)worst;
+}
+
 __global__ __launch_bounds__(256) void k2_energy(const double* __restrict__ f, const int8_t* __restrict__ s,
                                                 const double* __restrict__ bias, double* __restrict__ out, int n) {
     // f = J s + b  =>  -1/2 s.(f - b) - b.s
@@ -743,6 +881,33 @@ int tsu_dense_sweep(tsu_dense* d, double T, int n_sweeps, const int64_t* order, 
                                         TSU_TAG_DENSE | (replica << 8), (uint32_t)seed, (uint32_t)(seed >> 32)));
             return TSU_OK;
         }
+    }
+    static int use_wg = -1;
+    if (use_wg < 0) {
+        const char* e = getenv("TSU_K2_WG");
+        use_wg = e ? atoi(e) : -1;  // largest n on the one-workgroup kernel (0: never; default: where it beats the grid-wide path)
+        if (use_wg > K2WG_MAX_N) use_wg = K2WG_MAX_N;
+    }
+    // measured crossover against the cooperative kernel (tools/dense_mid_times.py): fp32 J ~600 sites, fp64 J ~470
+    if (!order && d->n <= (use_wg >= 0 ? use_wg : (d->dtype == TSU_DTYPE_F64 ? 448 : 576))) {
+        // mid-size systems: one workgroup, thread per site, all sweeps of the call in one launch
+        const unsigned threads = (unsigned)((d->n + 63) / 64 * 64);
+        const uint32_t tag = TSU_TAG_DENSE | (replica << 8);
+        static const bool verbose_wg = getenv("TSU_K2_VERBOSE") != nullptr;
+        if (d->dtype == TSU_DTYPE_F64)
+            k2_wg<double><<<1, threads, 0, ctx->stream>>>((const double*)d->JT, d->bias, d->state, replay_uniforms ? d->uniforms : nullptr, d->n, T,
+                                                        n_sweeps, sweep0, tag, (uint32_t)seed, (uint32_t)(seed >> 32), verbose_wg ? (unsigned*)d->d_energy : nullptr);
+        else
+            k2_wg<float><<<1, threads, 0, ctx->stream>>>((const float*)d->JT, d->bias, d->state, replay_uniforms ? d->uniforms : nullptr, d->n, T,
+                                                       n_sweeps, sweep0, tag, (uint32_t)seed, (uint32_t)(seed >> 32), verbose_wg ? (unsigned*)d->d_energy : nullptr);
+        TSU_HIP_TRY(ctx, hipGetLastError());
+        if (verbose_wg) {
+            unsigned w = 0;
+            TSU_HIP_TRY(ctx, hipMemcpyAsync(&w, d->d_energy, 4, hipMemcpyDeviceToHost, ctx->stream));
+            TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            fprintf(stderr, "[tsu] k2_wg n=%d: %d sweeps, slowest fixed point %u iterations\n", d->n, n_sweeps, w);
+        }
+        return TSU_OK;
     }
     static int use_sb = -1, use_coop = -1;
     if (use_sb < 0) {
