@@ -5,8 +5,11 @@
 // (gibbs.py:73-77), s_i <- (u < p) (gibbs.py:126).  The visiting order is the reference's (range(n) or
 // the caller's permutation); what is parallel is the arithmetic, not the Markov chain.
 //
-// Three paths, the same results (dispatch in tsu_dense_sweep):
-//   * natural order, n >= 128: dense_coop.hip -- the whole call in one cooperative launch (superblock fixed point);
+// Paths, all with the same results (dispatch in tsu_dense_sweep), natural order by system size:
+//   * k2_small (n <= 192 fp32 J / 128 fp64 J): a whole call (or sample_boltzmann run, annealing schedule, tempering
+//     ladder) in one launch of a single wave, J in LDS;
+//   * k2_wg (n <= 576 / 448): one workgroup, a thread per site, J^T columns from L2;
+//   * larger: dense_coop.hip -- the whole call in one cooperative launch (superblock fixed point);
 //   * the same fixed point with one launch per iteration (k2_sb_iter / k2_sb_finish) when a cooperative launch is
 //     not available;
 //   * k2_block: per sweep the field f = J s + b (k2_matvec), then the visiting order in blocks of 64 positions, one
@@ -15,7 +18,6 @@
 //     earlier site of the block actually flips), and the block's flips are added to the other fields through rows
 //     of J^T.  Serves custom visiting orders (np.random.permutation), tiny systems and the never-seen case of a
 //     superblock that did not converge.
-//   * k2_small (n <= 64, natural order): a whole sample_boltzmann run in one launch of a single wave.
 //
 // Uniforms: replayed doubles from the host (bit-exact replay of np.random.rand) or Philox doubles keyed by
 // (site, sweep): a = W[2(i&1)] >> 5, b = W[2(i&1)+1] >> 6, u = (a 2^26 + b) / 2^53 with
