@@ -426,6 +426,28 @@ def test_dense_sample_run_matches_oracle(hip, n, dtype):
     d.close()
 
 
+@pytest.mark.parametrize("n,dtype", [(15, "f64"), (100, "f32"), (150, "f64"), (300, "f32"), (700, "f32")])
+def test_dense_anneal_schedule_matches_oracle(hip, n, dtype):
+    """tsu_dense_anneal (one sweep per temperature of a schedule, every state recorded, one call): one wave, one workgroup
+    or one tsu_dense_sweep per step depending on the size -- the same chain as the oracle swept step by step."""
+    rng = np.random.default_rng(7 + n)
+    J = rng.normal(size=(n, n)) / np.sqrt(n)
+    J = (J + J.T) / 2
+    if dtype == "f32":
+        J = J.astype(np.float32).astype(np.float64)
+    st = rng.integers(0, 2, size=n).astype(np.int8)
+    temps = 5.0 * (0.02 / 5.0) ** (np.arange(70) / 70.0)  # the reference's exponential schedule (gibbs.py:375-377)
+    d = hip.DenseSystem(J, None, hip.DTYPE_F64 if dtype == "f64" else hip.DTYPE_F32)
+    d.set_state(st)
+    got = d.anneal(temps, seed=99, sweep0=3)
+    cur = st
+    for k, T in enumerate(temps):
+        cur = ora.dense_sweep_philox(cur, J, None, float(T), 1, 99, sweep0=3 + k)
+        np.testing.assert_array_equal(got[k], cur)
+    np.testing.assert_array_equal(d.get_state(), cur)
+    d.close()
+
+
 @pytest.mark.parametrize("n", [10, 64, 100, 128, 130])
 def test_dense_sweep_replicas_match_oracle(hip, n):
     """tsu_dense_sweep_replicas (a tempering ladder's replica loop in one call; one wave per replica for n <= 64):

@@ -318,6 +318,18 @@ __global__ __launch_bounds__(64) void k2_small_replicas(const TJ* __restrict__ J
                         rp.T, nullptr, n_sweeps, 1, 0, rp.sweep0, rp.tag, rp.k0, rp.k1);
 }
 
+// largest n on the one-workgroup kernel: the measured crossover against the cooperative kernel
+// (tools/dense_mid_times.py): fp32 J ~600 sites, fp64 J ~470; TSU_K2_WG=n overrides (0: never)
+static bool k2wg_takes(const tsu_dense* d) {
+    static int use_wg = -2;
+    if (use_wg == -2) {
+        const char* e = getenv("TSU_K2_WG");
+        use_wg = e ? atoi(e) : -1;
+        if (use_wg > 1024) use_wg = 1024;
+    }
+    return d->n <= (use_wg >= 0 ? use_wg : (d->dtype == TSU_DTYPE_F64 ? 448 : 576));
+}
+
 // slots per lane the one-wave kernels need for this system, 0 if it does not fit one CU's LDS (TSU_K2_WAVE=0: at most 1)
 static int k2w_slots(const tsu_dense* d) {
     static int enabled = -1;
@@ -475,17 +487,27 @@ static __device__ __forceinline__ double k2wg_apply(__amdgpu_buffer_rsrc_t JT, c
 
 template <typename TJ>
 __global__ __launch_bounds__(1024) void k2_wg(const TJ* __restrict__ JTp, const double* __restrict__ bias, int8_t* __restrict__ state,
-                                             const double* __restrict__ uniforms, int n, double T, int n_sweeps, uint32_t sweep0,
-                                             uint32_t tag, uint32_t k0, uint32_t k1, unsigned* __restrict__ info) {
+                                             const double* __restrict__ uniforms, int8_t* __restrict__ samples, int n, double T,
+                                             const double* __restrict__ temps, int n_burnin, int n_per_sample, int n_samples,
+                                             uint32_t sweep0, uint32_t tag, uint32_t k0, uint32_t k1, unsigned* __restrict__ info) {
+    // n_burnin sweeps, then n_samples x (n_per_sample sweeps, record the state) -- a plain sweep call is (n, 1, 0);
+    // temps: one temperature per sweep (an annealing schedule) or NULL
     __shared__ K2wgList L;
     const __amdgpu_buffer_rsrc_t JT = __builtin_amdgcn_make_buffer_rsrc(const_cast<TJ*>(JTp), 0, n * n * (int)sizeof(TJ), 0x00020000);
     const int i = threadIdx.x, lane = i & 63, wave = i >> 6, nwaves = blockDim.x >> 6;
     const bool on = i < n;
-    const double invT = 1.0 / T, b = (on && bias) ? bias[i] : 0.0;
+    const double b = (on && bias) ? bias[i] : 0.0;
+    double invT = 1.0 / T;
     int bit = on ? state[i] : 0;
     double f = 0.0;
     int worst = 0;
+    const int n_sweeps = n_burnin + n_samples * n_per_sample;
+    int next_record = n_burnin + n_per_sample - 1, rec = 0;
     for (int sw = 0; sw < n_sweeps; ++sw) {
+        if (temps) {
+            T = temps[sw];
+            invT = 1.0 / T;
+        }
         if (sw % K2WG_REFRESH == 0) {  // fields from scratch: b + sum over the sites that are up of their column
             const int cnt = k2wg_build(L, on && bit != 0, 1, i, wave, lane, nwaves);
             f = k2wg_apply<TJ, false>(JT, L, cnt, n, i, lane, on, b);
@@ -505,6 +527,11 @@ __global__ __launch_bounds__(1024) void k2_wg(const TJ* __restrict__ JTp, const 
         }
         if (iter > worst) worst = iter;
         bit += d_prev;
+        if (samples && sw == next_record) {
+            if (on) samples[(size_t)rec * n + i] = (int8_t)bit;
+            ++rec;
+            next_record += n_per_sample;
+        }
         if (sw + 1 < n_sweeps && (sw + 1) % K2WG_REFRESH != 0) {  // hand the fields on: every flip, every row
             const int cnt = k2wg_build(L, d_prev != 0, d_prev, i, wave, lane, nwaves);
             f = k2wg_apply<TJ, false>(JT, L, cnt, n, i, lane, on, f);
@@ -512,6 +539,19 @@ __global__ __launch_bounds__(1024) void k2_wg(const TJ* __restrict__ JTp, const 
     }
     if (on) state[i] = (int8_t)bit;
     if (i == 0 && info) info[0] = (unsigned)worst;
+}
+
+static hipError_t k2wg_launch(const tsu_dense* d, hipStream_t stream, const double* uniforms, int8_t* samples, double T, const double* temps,
+                               int n_burnin, int n_per_sample, int n_samples, uint32_t sweep0, uint32_t tag, uint32_t k0, uint32_t k1,
+                               unsigned* info) {
+    const unsigned threads = (unsigned)((d->n + 63) / 64 * 64);
+    if (d->dtype == TSU_DTYPE_F64)
+        k2_wg<double><<<1, threads, 0, stream>>>((const double*)d->JT, d->bias, d->state, uniforms, samples, d->n, T, temps, n_burnin, n_per_sample,
+                                               n_samples, sweep0, tag, k0, k1, info);
+    else
+        k2_wg<float><<<1, threads, 0, stream>>>((const float*)d->JT, d->bias, d->state, uniforms, samples, d->n, T, temps, n_burnin, n_per_sample,
+                                              n_samples, sweep0, tag, k0, k1, info);
+    return hipGetLastError();
 }
 
 __global__ __launch_bounds__(256) void k2_energy(const double* __restrict__ f, const int8_t* __restrict__ s,
@@ -884,25 +924,12 @@ int tsu_dense_sweep(tsu_dense* d, double T, int n_sweeps, const int64_t* order, 
             return TSU_OK;
         }
     }
-    static int use_wg = -1;
-    if (use_wg < 0) {
-        const char* e = getenv("TSU_K2_WG");
-        use_wg = e ? atoi(e) : -1;  // largest n on the one-workgroup kernel (0: never; default: where it beats the grid-wide path)
-        if (use_wg > K2WG_MAX_N) use_wg = K2WG_MAX_N;
-    }
-    // measured crossover against the cooperative kernel (tools/dense_mid_times.py): fp32 J ~600 sites, fp64 J ~470
-    if (!order && d->n <= (use_wg >= 0 ? use_wg : (d->dtype == TSU_DTYPE_F64 ? 448 : 576))) {
+    if (!order && k2wg_takes(d)) {
         // mid-size systems: one workgroup, thread per site, all sweeps of the call in one launch
-        const unsigned threads = (unsigned)((d->n + 63) / 64 * 64);
-        const uint32_t tag = TSU_TAG_DENSE | (replica << 8);
         static const bool verbose_wg = getenv("TSU_K2_VERBOSE") != nullptr;
-        if (d->dtype == TSU_DTYPE_F64)
-            k2_wg<double><<<1, threads, 0, ctx->stream>>>((const double*)d->JT, d->bias, d->state, replay_uniforms ? d->uniforms : nullptr, d->n, T,
-                                                        n_sweeps, sweep0, tag, (uint32_t)seed, (uint32_t)(seed >> 32), verbose_wg ? (unsigned*)d->d_energy : nullptr);
-        else
-            k2_wg<float><<<1, threads, 0, ctx->stream>>>((const float*)d->JT, d->bias, d->state, replay_uniforms ? d->uniforms : nullptr, d->n, T,
-                                                       n_sweeps, sweep0, tag, (uint32_t)seed, (uint32_t)(seed >> 32), verbose_wg ? (unsigned*)d->d_energy : nullptr);
-        TSU_HIP_TRY(ctx, hipGetLastError());
+        TSU_HIP_TRY(ctx, k2wg_launch(d, ctx->stream, replay_uniforms ? d->uniforms : nullptr, nullptr, T, nullptr, n_sweeps, 1, 0, sweep0,
+                                     TSU_TAG_DENSE | (replica << 8), (uint32_t)seed, (uint32_t)(seed >> 32),
+                                     verbose_wg ? (unsigned*)d->d_energy : nullptr));
         if (verbose_wg) {
             unsigned w = 0;
             TSU_HIP_TRY(ctx, hipMemcpyAsync(&w, d->d_energy, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -973,7 +1000,8 @@ static int dense_run(tsu_dense* d, double T, const double* temps, int n_burnin, 
         d->samples_cap = out_bytes;
     }
     const int wave_m = order ? 0 : k2w_slots(d);
-    if (wave_m) {
+    const bool wg = !order && !wave_m && k2wg_takes(d);
+    if (wave_m || wg) {
         const double* temps_dev = nullptr;
         if (temps && total > 0) {
             if (d->temps_cap < (size_t)total) {
@@ -999,9 +1027,12 @@ static int dense_run(tsu_dense* d, double T, const double* temps, int n_burnin, 
             TSU_HIP_TRY(ctx, hipMemcpyAsync(d->uniforms, replay_uniforms, cnt * 8, hipMemcpyHostToDevice, ctx->stream));
         }
         const uint32_t tag = TSU_TAG_DENSE | (replica << 8);
-        if (total > 0)
+        if (total > 0 && wave_m)
             TSU_HIP_TRY(ctx, k2w_launch(d, wave_m, ctx->stream, replay_uniforms ? d->uniforms : nullptr, d->samples, T, temps_dev, n_burnin, n_sweeps,
                                         n_samples, sweep0, tag, (uint32_t)seed, (uint32_t)(seed >> 32)));
+        else if (total > 0)
+            TSU_HIP_TRY(ctx, k2wg_launch(d, ctx->stream, replay_uniforms ? d->uniforms : nullptr, d->samples, T, temps_dev, n_burnin, n_sweeps,
+                                         n_samples, sweep0, tag, (uint32_t)seed, (uint32_t)(seed >> 32), nullptr));
     } else {
         // larger systems: the sweep paths above, one call per recorded state; samples gathered on the device
         // (with a schedule every recorded state is one sweep: n_burnin == 0 and n_sweeps == 1)
