@@ -183,7 +183,7 @@ int tsu_dense_anneal(tsu_dense* d, const double* temperatures, int n_steps, cons
 /* The replica loop of GibbsSampler.parallel_tempering (tsu/gibbs.py:300-306): replica r does n_sweeps sweeps of its own
  * state (states_host[r*n .. ], in and out) at temperatures[r] with its own seed / sweep counter / replica id;
  * replay_uniforms: NULL or n_replicas * n_sweeps * n doubles.  The handle's resident state is not used.  n <= 192 (fp32 J; 128 for fp64): one
- * launch, one wave per replica; larger systems are swept one replica after the other. */
+ * launch, one wave per replica; up to 576 (448) sites one workgroup per replica; larger systems are swept one replica after the other. */
 int tsu_dense_sweep_replicas(tsu_dense* d, int n_replicas, const double* temperatures, int n_sweeps, int8_t* states_host,
                              const uint64_t* seeds, const uint32_t* sweep0s, const uint32_t* replicas,
                              const double* replay_uniforms);

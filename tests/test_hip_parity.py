@@ -448,7 +448,7 @@ def test_dense_anneal_schedule_matches_oracle(hip, n, dtype):
     d.close()
 
 
-@pytest.mark.parametrize("n", [10, 64, 100, 128, 130])
+@pytest.mark.parametrize("n", [10, 64, 100, 128, 130, 300, 500])
 def test_dense_sweep_replicas_match_oracle(hip, n):
     """tsu_dense_sweep_replicas (a tempering ladder's replica loop in one call; one wave per replica for n <= 64):
     each replica == the oracle's chain at its temperature / seed / counter; replayed uniforms likewise."""

@@ -489,10 +489,22 @@ template <typename TJ>
 __global__ __launch_bounds__(1024) void k2_wg(const TJ* __restrict__ JTp, const double* __restrict__ bias, int8_t* __restrict__ state,
                                              const double* __restrict__ uniforms, int8_t* __restrict__ samples, int n, double T,
                                              const double* __restrict__ temps, int n_burnin, int n_per_sample, int n_samples,
-                                             uint32_t sweep0, uint32_t tag, uint32_t k0, uint32_t k1, unsigned* __restrict__ info) {
+                                             uint32_t sweep0, uint32_t tag, uint32_t k0, uint32_t k1, unsigned* __restrict__ info,
+                                             const K2Replica* __restrict__ reps) {
     // n_burnin sweeps, then n_samples x (n_per_sample sweeps, record the state) -- a plain sweep call is (n, 1, 0);
-    // temps: one temperature per sweep (an annealing schedule) or NULL
+    // temps: one temperature per sweep (an annealing schedule) or NULL; reps: workgroup r sweeps state r of a tempering
+    // ladder at its own temperature with its own stream (its uniforms follow those of replica r - 1)
     __shared__ K2wgList L;
+    if (reps) {
+        const K2Replica rp = reps[blockIdx.x];
+        T = rp.T;
+        sweep0 = rp.sweep0;
+        tag = rp.tag;
+        k0 = rp.k0;
+        k1 = rp.k1;
+        state += (size_t)blockIdx.x * n;
+        if (uniforms) uniforms += (size_t)blockIdx.x * n_burnin * n;
+    }
     const __amdgpu_buffer_rsrc_t JT = __builtin_amdgcn_make_buffer_rsrc(const_cast<TJ*>(JTp), 0, n * n * (int)sizeof(TJ), 0x00020000);
     const int i = threadIdx.x, lane = i & 63, wave = i >> 6, nwaves = blockDim.x >> 6;
     const bool on = i < n;
@@ -543,14 +555,15 @@ __global__ __launch_bounds__(1024) void k2_wg(const TJ* __restrict__ JTp, const 
 
 static hipError_t k2wg_launch(const tsu_dense* d, hipStream_t stream, const double* uniforms, int8_t* samples, double T, const double* temps,
                                int n_burnin, int n_per_sample, int n_samples, uint32_t sweep0, uint32_t tag, uint32_t k0, uint32_t k1,
-                               unsigned* info) {
+                               unsigned* info, int n_replicas = 1, int8_t* states = nullptr, const K2Replica* reps = nullptr) {
     const unsigned threads = (unsigned)((d->n + 63) / 64 * 64);
+    int8_t* st = reps ? states : d->state;
     if (d->dtype == TSU_DTYPE_F64)
-        k2_wg<double><<<1, threads, 0, stream>>>((const double*)d->JT, d->bias, d->state, uniforms, samples, d->n, T, temps, n_burnin, n_per_sample,
-                                               n_samples, sweep0, tag, k0, k1, info);
+        k2_wg<double><<<(unsigned)n_replicas, threads, 0, stream>>>((const double*)d->JT, d->bias, st, uniforms, samples, d->n, T, temps, n_burnin,
+                                                                  n_per_sample, n_samples, sweep0, tag, k0, k1, info, reps);
     else
-        k2_wg<float><<<1, threads, 0, stream>>>((const float*)d->JT, d->bias, d->state, uniforms, samples, d->n, T, temps, n_burnin, n_per_sample,
-                                              n_samples, sweep0, tag, k0, k1, info);
+        k2_wg<float><<<(unsigned)n_replicas, threads, 0, stream>>>((const float*)d->JT, d->bias, st, uniforms, samples, d->n, T, temps, n_burnin,
+                                                                 n_per_sample, n_samples, sweep0, tag, k0, k1, info, reps);
     return hipGetLastError();
 }
 
@@ -1083,7 +1096,8 @@ int tsu_dense_sweep_replicas(tsu_dense* d, int n_replicas, const double* tempera
     }
     if (n_sweeps == 0) return TSU_OK;
     const int wave_m = k2w_slots(d);
-    if (!wave_m) {  // larger systems: one replica after the other through the sweep paths
+    const bool wg = !wave_m && k2wg_takes(d);
+    if (!wave_m && !wg) {  // larger systems: one replica after the other through the sweep paths
         for (int r = 0; r < n_replicas; ++r) {
             int rc = tsu_dense_set_state(d, states_host + (size_t)r * n);
             if (rc == TSU_OK)
@@ -1118,7 +1132,10 @@ int tsu_dense_sweep_replicas(tsu_dense* d, int n_replicas, const double* tempera
     TSU_HIP_TRY(ctx, hipMemcpyAsync(d_states, states_host, sbytes, hipMemcpyHostToDevice, ctx->stream));
     if (ubytes) TSU_HIP_TRY(ctx, hipMemcpyAsync(d_uni, replay_uniforms, ubytes, hipMemcpyHostToDevice, ctx->stream));
     TSU_HIP_TRY(ctx, hipMemcpyAsync(d_reps, reps.data(), rbytes, hipMemcpyHostToDevice, ctx->stream));
-    TSU_HIP_TRY(ctx, k2w_launch_replicas(d, wave_m, ctx->stream, n_replicas, d_states, d_uni, d_reps, n_sweeps));
+    if (wave_m)
+        TSU_HIP_TRY(ctx, k2w_launch_replicas(d, wave_m, ctx->stream, n_replicas, d_states, d_uni, d_reps, n_sweeps));
+    else  // one workgroup per replica
+        TSU_HIP_TRY(ctx, k2wg_launch(d, ctx->stream, d_uni, nullptr, 1.0, nullptr, n_sweeps, 1, 0, 0, 0, 0, 0, nullptr, n_replicas, d_states, d_reps));
     TSU_HIP_TRY(ctx, hipMemcpyAsync(states_host, d_states, sbytes, hipMemcpyDeviceToHost, ctx->stream));
     TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TSU_OK;
