@@ -492,23 +492,51 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
         const uint64_t* X_ur = xg + (size_t)(tyu * tiles_x + txr) * xstride;
         const uint64_t* X_dl = xg + (size_t)(tyd * tiles_x + txl) * xstride;
         const uint64_t* X_dr = xg + (size_t)(tyd * tiles_x + txr) * xstride;
-        // halo rows: top [0, 2k) from the BOTTOM strips above, bottom [2k + H, TR) from the TOP strips below
-        for (int i = tid; i < 2 * 2 * k * NO; i += THREADS) {
-            const int pl = i / (2 * k * NO), rem = i - pl * (2 * k * NO), r = rem / NO, o = rem - r * NO;
-            uint64_t* P = pl ? plane1 : plane0;
+        // halo rows: top [0, 2k) from the BOTTOM strips above, bottom [2k + H, TR) from the TOP strips below; halo octets of the
+        // interior rows: octet 0 from the left neighbour's RIGHT strip, octet NO-1 from the right one's LEFT.  Every load of
+        // a thread is issued before the first is stored (one round trip to the coherence point for the whole refresh, not one
+        // per loop iteration), and unconditionally: a neighbour index always names a real tile, a missing neighbour's
+        // value is just not stored.
+        constexpr int FI = (2 * 2 * 8 * NO + THREADS - 1) / THREADS;   // k <= 8
+        constexpr int TH_MAX = 160 * 1024 / 8 / (2 * NO) - 32;         // tallest (stretched slab) tile whose planes fit the CU's LDS
+        constexpr int SI = (2 * TH_MAX + THREADS - 1) / THREADS;
+        uint64_t vu[FI], vd[FI], vl[SI], vr[SI];
+#pragma unroll
+        for (int it = 0; it < FI; ++it) {
+            const int i = tid + it * THREADS, ic = i < 2 * 2 * k * NO ? i : 0;
+            const int pl = ic / (2 * k * NO), rem = ic - pl * (2 * k * NO), r = rem / NO, o = rem - r * NO;
             const int e = pl * n_tb + r * WO;
             const uint64_t* pu = o == 0 ? X_ul + 2 * n_tb + e + WO - 1 : (o == NO - 1 ? X_ur + 2 * n_tb + e : X_u + 2 * n_tb + e + o - 1);
             const uint64_t* pd = o == 0 ? X_dl + e + WO - 1 : (o == NO - 1 ? X_dr + e : X_d + e + o - 1);
-            const bool col_ok = o == 0 ? has_l : (o == NO - 1 ? has_r : true);
-            if (has_u && col_ok) P[r * NO + o] = xld(pu);
-            if (has_d && col_ok) P[(2 * k + H + r) * NO + o] = xld(pd);
+            vu[it] = xld(pu);
+            vd[it] = xld(pd);
         }
-        // halo octets of the interior rows: octet 0 from the left neighbour's RIGHT strip, octet NO-1 from the right one's LEFT
-        for (int i = tid; i < 2 * n_lr; i += THREADS) {
-            const int pl = i / n_lr, r = i - pl * n_lr;
-            uint64_t* P = pl ? plane1 : plane0;
-            if (has_l) P[(2 * k + r) * NO] = xld(X_l + 4 * n_tb + 2 * n_lr + i);
-            if (has_r) P[(2 * k + r) * NO + NO - 1] = xld(X_r + 4 * n_tb + i);
+#pragma unroll
+        for (int it = 0; it < SI; ++it) {
+            const int i = tid + it * THREADS, ic = i < 2 * n_lr ? i : 0;
+            vl[it] = xld(X_l + 4 * n_tb + 2 * n_lr + ic);
+            vr[it] = xld(X_r + 4 * n_tb + ic);
+        }
+#pragma unroll
+        for (int it = 0; it < FI; ++it) {
+            const int i = tid + it * THREADS;
+            if (i < 2 * 2 * k * NO) {
+                const int pl = i / (2 * k * NO), rem = i - pl * (2 * k * NO), r = rem / NO, o = rem - r * NO;
+                uint64_t* P = pl ? plane1 : plane0;
+                const bool col_ok = o == 0 ? has_l : (o == NO - 1 ? has_r : true);
+                if (has_u && col_ok) P[r * NO + o] = vu[it];
+                if (has_d && col_ok) P[(2 * k + H + r) * NO + o] = vd[it];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < SI; ++it) {
+            const int i = tid + it * THREADS;
+            if (i < 2 * n_lr) {
+                const int pl = i / n_lr, r = i - pl * n_lr;
+                uint64_t* P = pl ? plane1 : plane0;
+                if (has_l) P[(2 * k + r) * NO] = vl[it];
+                if (has_r) P[(2 * k + r) * NO + NO - 1] = vr[it];
+            }
         }
         RES_MARK(3);
     }
