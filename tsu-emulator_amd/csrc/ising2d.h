@@ -23,6 +23,8 @@ struct tsu_ising2d {
     int* d_sync;         // tile-resident kernel: per-tile generation counters
     uint64_t* d_xbuf;    // tile-resident kernel: exchange strips
     size_t xbuf_cap;
+    uint32_t xgen;       // generations numbered so far in d_xbuf (every strip element carries its generation number)
+    uint64_t xsig;       // strip layout the numbering belongs to (0: buffer not cleared yet)
     void* d_batch;       // tsu_ising2d_sweep_batch: device copy of the per-lattice launch items
     size_t batch_cap;
     void* d_obs_batch;   // tsu_ising2d_observables_batch: [n][2] sums of the batch (lives with its first lattice)

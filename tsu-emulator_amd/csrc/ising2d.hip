@@ -446,6 +446,8 @@ int tsu_ising2d_create_slab(tsu_ctx* ctx, int64_t total_rows, int cols, int peri
     L->d_sync = nullptr;
     L->d_xbuf = nullptr;
     L->xbuf_cap = 0;
+    L->xgen = 0;
+    L->xsig = 0;
     L->d_batch = nullptr;
     L->batch_cap = 0;
     L->d_obs_batch = nullptr;

@@ -274,8 +274,8 @@ static __device__ __forceinline__ void xst(uint64_t* p, uint64_t v) { __hip_atom
 static __device__ __forceinline__ uint64_t xld(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 struct ResidentParams {
-    uint64_t* xbuf;  // [2 parities][tiles][XSTRIDE] exchange strips
-    int* done;       // [tiles] generations published
+    uint64_t* xbuf;  // [2 parities][tiles][XSTRIDE] exchange strips; every element carries its generation number (see tile_body)
+    uint32_t gen0;   // number of the first generation this launch publishes (1 .. 16383, counted on from launch to launch)
     int* err;        // host-mapped: set if a bounded wait expired (results invalid)
     int n_gen, k_last, tiles_y;
     int wrap_y;      // tile rows wrap (whole periodic lattice); 0 for a slab: its outer tile rows have no neighbour there and
@@ -443,46 +443,32 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
         const int n_tb = 2 * k * WO, n_lr = H;                  // elements per plane of a top/bottom and a left/right strip
         const int xstride = 4 * n_tb + 4 * n_lr;                 // TOP[2][n_tb] BOTTOM[2][n_tb] LEFT[2][n_lr] RIGHT[2][n_lr]
         uint64_t* mine = R->xbuf + ((size_t)(gen & 1) * ntiles + me) * xstride;
+        // Every strip element (8 up-flags, one per byte) carries the 14-bit number of its generation in the spare bits 1..7
+        // of its bytes 0 and 1, so a reader validates each element by itself: no "strips complete" flag, no wait for the
+        // stores to be acknowledged before raising one, no wait for the flag before fetching -- the refresh is a single
+        // round trip that is repeated only for the elements that were not there yet.  (A slot is rewritten every second
+        // generation and neighbours are never more than one generation apart, so a stale element always carries another
+        // number; the host clears the buffer when the numbering restarts or the strip layout changes.)
+        const uint32_t G = R->gen0 + (uint32_t)gen;
+        const uint64_t tag = ((uint64_t)(G & 0x7Fu) << 1) | ((uint64_t)((G >> 7) & 0x7Fu) << 9);
+        constexpr uint64_t TAG_MASK = 0xFEFEull, FLAG_MASK = 0x0101010101010101ull;
         for (int i = tid; i < 2 * n_tb; i += THREADS) {
             const int pl = i / n_tb, rem = i - pl * n_tb, r = rem / WO, o = rem - r * WO;
             const uint64_t* P = pl ? plane1 : plane0;
-            xst(mine + i, P[(2 * k + r) * NO + 1 + o]);           // TOP: first 2k interior rows
-            xst(mine + 2 * n_tb + i, P[(H + r) * NO + 1 + o]);    // BOTTOM: last 2k interior rows
+            xst(mine + i, P[(2 * k + r) * NO + 1 + o] | tag);           // TOP: first 2k interior rows
+            xst(mine + 2 * n_tb + i, P[(H + r) * NO + 1 + o] | tag);    // BOTTOM: last 2k interior rows
         }
         for (int i = tid; i < 2 * n_lr; i += THREADS) {
             const int pl = i / n_lr, r = i - pl * n_lr;
             const uint64_t* P = pl ? plane1 : plane0;
-            xst(mine + 4 * n_tb + i, P[(2 * k + r) * NO + 1]);             // LEFT: first interior octet
-            xst(mine + 4 * n_tb + 2 * n_lr + i, P[(2 * k + r) * NO + WO]); // RIGHT: last interior octet
+            xst(mine + 4 * n_tb + i, P[(2 * k + r) * NO + 1] | tag);             // LEFT: first interior octet
+            xst(mine + 4 * n_tb + 2 * n_lr + i, P[(2 * k + r) * NO + WO] | tag); // RIGHT: last interior octet
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(R->done + me, gen + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         RES_MARK(1);
         const int txl = tx == 0 ? tiles_x - 1 : tx - 1, txr = tx == tiles_x - 1 ? 0 : tx + 1;
         const int tyu = ty == 0 ? tiles_y - 1 : ty - 1, tyd = ty == tiles_y - 1 ? 0 : ty + 1;
         const bool has_u = R->wrap_y || ty > 0, has_d = R->wrap_y || ty < tiles_y - 1;
         const bool has_l = R->wrap_x || tx > 0, has_r = R->wrap_x || tx < tiles_x - 1;
-        if (tid < 8) {  // the eight neighbours (periodic in tiles), one lane each
-            const int nx = (tid == 0 || tid == 3 || tid == 5) ? txl : ((tid == 2 || tid == 4 || tid == 7) ? txr : tx);
-            const int ny = tid < 3 ? tyu : (tid < 5 ? ty : tyd);
-            const int* flag = R->done + ny * tiles_x + nx;
-            const bool exists = (tid < 3 ? has_u : (tid < 5 ? true : has_d)) &&
-                                ((tid == 0 || tid == 3 || tid == 5) ? has_l : ((tid == 2 || tid == 4 || tid == 7) ? has_r : true));
-            int spins = 0;
-            while (exists && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen + 1) {
-                __builtin_amdgcn_s_sleep(2);
-                // the error flag lives in host memory (a PCIe round trip): look at it rarely
-                if (++spins > (1 << 23) || ((spins & 0xFFF) == 0 && __hip_atomic_load(R->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))) {
-                    __hip_atomic_store(R->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // ~seconds: grid not co-resident
-                    s_fail = 1;
-                    break;
-                }
-            }
-        }
-        __syncthreads();
-        if (s_fail) return;  // nothing is stored: the source buffer stays valid
-        RES_MARK(2);
         const uint64_t* xg = R->xbuf + (size_t)(gen & 1) * ntiles * xstride;
         const uint64_t* X_u = xg + (size_t)(tyu * tiles_x + tx) * xstride;
         const uint64_t* X_d = xg + (size_t)(tyd * tiles_x + tx) * xstride;
@@ -494,38 +480,67 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
         const uint64_t* X_dr = xg + (size_t)(tyd * tiles_x + txr) * xstride;
         // halo rows: top [0, 2k) from the BOTTOM strips above, bottom [2k + H, TR) from the TOP strips below; halo octets of the
         // interior rows: octet 0 from the left neighbour's RIGHT strip, octet NO-1 from the right one's LEFT.  Every load of
-        // a thread is issued before the first is stored (one round trip to the coherence point for the whole refresh, not one
-        // per loop iteration), and unconditionally: a neighbour index always names a real tile, a missing neighbour's
-        // value is just not stored.
+        // a thread is issued before the first is looked at, and unconditionally: a neighbour index always names a real
+        // tile, a missing neighbour's value is neither checked nor stored.
         constexpr int FI = (2 * 2 * 8 * NO + THREADS - 1) / THREADS;   // k <= 8
         constexpr int TH_MAX = 160 * 1024 / 8 / (2 * NO) - 32;         // tallest (stretched slab) tile whose planes fit the CU's LDS
         constexpr int SI = (2 * TH_MAX + THREADS - 1) / THREADS;
+        const uint64_t* au[FI];
+        const uint64_t* ad[FI];
         uint64_t vu[FI], vd[FI], vl[SI], vr[SI];
+        bool nu[FI], nd[FI], nl[SI], nr[SI];  // this thread needs the element
 #pragma unroll
         for (int it = 0; it < FI; ++it) {
             const int i = tid + it * THREADS, ic = i < 2 * 2 * k * NO ? i : 0;
             const int pl = ic / (2 * k * NO), rem = ic - pl * (2 * k * NO), r = rem / NO, o = rem - r * NO;
             const int e = pl * n_tb + r * WO;
-            const uint64_t* pu = o == 0 ? X_ul + 2 * n_tb + e + WO - 1 : (o == NO - 1 ? X_ur + 2 * n_tb + e : X_u + 2 * n_tb + e + o - 1);
-            const uint64_t* pd = o == 0 ? X_dl + e + WO - 1 : (o == NO - 1 ? X_dr + e : X_d + e + o - 1);
-            vu[it] = xld(pu);
-            vd[it] = xld(pd);
+            au[it] = o == 0 ? X_ul + 2 * n_tb + e + WO - 1 : (o == NO - 1 ? X_ur + 2 * n_tb + e : X_u + 2 * n_tb + e + o - 1);
+            ad[it] = o == 0 ? X_dl + e + WO - 1 : (o == NO - 1 ? X_dr + e : X_d + e + o - 1);
+            const bool col_ok = o == 0 ? has_l : (o == NO - 1 ? has_r : true);
+            nu[it] = i < 2 * 2 * k * NO && has_u && col_ok;
+            nd[it] = i < 2 * 2 * k * NO && has_d && col_ok;
+            vu[it] = xld(au[it]);
+            vd[it] = xld(ad[it]);
         }
 #pragma unroll
         for (int it = 0; it < SI; ++it) {
             const int i = tid + it * THREADS, ic = i < 2 * n_lr ? i : 0;
+            nl[it] = i < 2 * n_lr && has_l;
+            nr[it] = i < 2 * n_lr && has_r;
             vl[it] = xld(X_l + 4 * n_tb + 2 * n_lr + ic);
             vr[it] = xld(X_r + 4 * n_tb + ic);
         }
+        // elements that are not of this generation yet: ask again (a neighbour that finished later; rare and short)
+        for (int spins = 0;; ++spins) {
+            bool fresh = true;
+#pragma unroll
+            for (int it = 0; it < FI; ++it) {
+                if (nu[it] && (vu[it] & TAG_MASK) != tag) { vu[it] = xld(au[it]); fresh = false; }
+                if (nd[it] && (vd[it] & TAG_MASK) != tag) { vd[it] = xld(ad[it]); fresh = false; }
+            }
+#pragma unroll
+            for (int it = 0; it < SI; ++it) {
+                const int i = tid + it * THREADS, ic = i < 2 * n_lr ? i : 0;
+                if (nl[it] && (vl[it] & TAG_MASK) != tag) { vl[it] = xld(X_l + 4 * n_tb + 2 * n_lr + ic); fresh = false; }
+                if (nr[it] && (vr[it] & TAG_MASK) != tag) { vr[it] = xld(X_r + 4 * n_tb + ic); fresh = false; }
+            }
+            if (fresh) break;
+            // the error flag lives in host memory (a PCIe round trip): look at it rarely
+            if (spins > (1 << 22) || ((spins & 0xFFF) == 0xFFF && __hip_atomic_load(R->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))) {
+                __hip_atomic_store(R->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // ~seconds: grid not co-resident
+                s_fail = 1;
+                break;
+            }
+        }
+        RES_MARK(2);
 #pragma unroll
         for (int it = 0; it < FI; ++it) {
             const int i = tid + it * THREADS;
             if (i < 2 * 2 * k * NO) {
                 const int pl = i / (2 * k * NO), rem = i - pl * (2 * k * NO), r = rem / NO, o = rem - r * NO;
                 uint64_t* P = pl ? plane1 : plane0;
-                const bool col_ok = o == 0 ? has_l : (o == NO - 1 ? has_r : true);
-                if (has_u && col_ok) P[r * NO + o] = vu[it];
-                if (has_d && col_ok) P[(2 * k + H + r) * NO + o] = vd[it];
+                if (nu[it]) P[r * NO + o] = vu[it] & FLAG_MASK;
+                if (nd[it]) P[(2 * k + H + r) * NO + o] = vd[it] & FLAG_MASK;
             }
         }
 #pragma unroll
@@ -534,10 +549,12 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
             if (i < 2 * n_lr) {
                 const int pl = i / n_lr, r = i - pl * n_lr;
                 uint64_t* P = pl ? plane1 : plane0;
-                if (has_l) P[(2 * k + r) * NO] = vl[it];
-                if (has_r) P[(2 * k + r) * NO + NO - 1] = vr[it];
+                if (nl[it]) P[(2 * k + r) * NO] = vl[it] & FLAG_MASK;
+                if (nr[it]) P[(2 * k + r) * NO + NO - 1] = vr[it] & FLAG_MASK;
             }
         }
+        __syncthreads();
+        if (s_fail) return;  // nothing is stored: the source buffer stays valid
         RES_MARK(3);
     }
     }  // generations
@@ -852,14 +869,10 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
                 L->xbuf_cap = 0;
                 TSU_HIP_TRY(ctx, hipMalloc(&L->d_xbuf, xneed * sizeof(uint64_t)));
                 L->xbuf_cap = xneed;
+                L->xsig = 0;  // fresh memory: cleared before its first use below
             }
-            if (L->sync_cap < (size_t)ntiles) {
-                if (L->d_sync) (void)hipFree(L->d_sync);
-                L->d_sync = nullptr;
-                L->sync_cap = 0;
-                TSU_HIP_TRY(ctx, hipMalloc(&L->d_sync, (size_t)ntiles * sizeof(int)));
-                L->sync_cap = (size_t)ntiles;
-            }
+            // strip layout of this call: the element numbering may only run on while it stays the same
+            const uint64_t xsig = ((uint64_t)(vi + 1) << 48) ^ ((uint64_t)ntiles << 28) ^ ((uint64_t)kmax << 20) ^ ((uint64_t)res_th << 4) ^ (uint64_t)p.open;
             if (!L->h_err) {
                 TSU_HIP_TRY(ctx, hipHostMalloc(&L->h_err, sizeof(int), hipHostMallocMapped));
                 *L->h_err = 0;
@@ -886,7 +899,14 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
                 P.r.wrap_y = L->wrap_rows ? 1 : 0;
                 P.r.wrap_x = L->periodic ? 1 : 0;
                 P.r.xbuf = L->d_xbuf;
-                P.r.done = L->d_sync;
+                if (L->xsig != xsig || L->xgen + (uint32_t)((chunk + kmax - 1) / kmax) + 2u >= 16383u) {
+                    // the numbering restarts (or another strip layout starts): no element may look like one of the new run
+                    TSU_HIP_TRY(ctx, hipMemsetAsync(L->d_xbuf, 0, L->xbuf_cap * sizeof(uint64_t), ctx->stream));
+                    L->xsig = xsig;
+                    L->xgen = 0;
+                }
+                P.r.gen0 = L->xgen + 1u;
+                L->xgen += (uint32_t)((chunk + kmax - 1) / kmax);
                 P.r.err = d_err;
                 P.r.n_gen = (chunk + kmax - 1) / kmax;
                 P.r.k_last = chunk - (P.r.n_gen - 1) * kmax;
@@ -904,7 +924,6 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
                     const int rcx = tsu_grid_exclusive_begin(ctx);
                     if (rcx != TSU_OK) return rcx;
                 }
-                TSU_HIP_TRY(ctx, hipMemsetAsync(L->d_sync, 0, (size_t)ntiles * sizeof(int), ctx->stream));
                 hipLaunchKernelGGL(res_kern, dim3((unsigned)ntiles), dim3((unsigned)tv.threads), lds_bytes, ctx->stream, P);
                 L->launches += 1;
                 L->cur ^= 1;
