@@ -264,12 +264,12 @@ static __device__ __forceinline__ void sweep_pairs(const Rows2Ctx& c, const Phil
 // Tile-resident generations (RESIDENT): when every tile of the lattice has its own workgroup on the chip at the same
 // time, a tile stays in LDS for many generations of k sweeps; after each generation it publishes the 2k interior rows
 // at its top and bottom and its first and last interior octet column (the colour planes as they are, ~20 KB) to a
-// global exchange buffer, raises its generation flag, waits for its eight neighbours' flags and refreshes its halo
-// from their strips.  The full-tile stage and store (87 + 64 KB per generation) and the launch gap
-// happen once per call instead of once per generation.
+// global exchange buffer and refreshes its halo from its eight neighbours' strips, whose elements carry their
+// generation number (no flags: see the exchange in tile_body).  The full-tile stage and store (87 + 64 KB per
+// generation) and the launch gap happen once per call instead of once per generation.
 // The strips travel through agent-scope relaxed atomic stores and loads (performed at the device's coherence point,
 // past the per-CU L1 and the per-XCD L2, like dense_coop.hip's shared data), so no cache write-back / invalidate is
-// needed around the flags: with release/acquire fences the publish step alone cost 5 us per generation.
+// needed: with release/acquire fences the publish step alone cost 5 us per generation.
 static __device__ __forceinline__ void xst(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 static __device__ __forceinline__ uint64_t xld(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
