@@ -177,6 +177,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # one rank per GPU; BENCH_BACKEND=gloo lets several ranks share a GPU (rehearsal of the N > 1 path on a 1-GPU box)
     backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if world > torch.cuda.device_count():
+        # rehearsal with several ranks on one GPU: two processes' tile-resident grids cannot both be on the chip, and half of
+        # each would wait for the other half for ever (reported as a timeout) -- one launch per generation there
+        os.environ.setdefault("TSU_K1_RESIDENT", "0")
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
@@ -198,8 +202,10 @@ def main():
     k = args.sweeps_per_launch or (8 if rows_local * L <= 4096 * 4096 else 5)
     if args.strong and world > 1 and not args.sweeps_per_launch:
         k = 8  # thin slabs run 256-row tiles, one per CU (tools/shape_scan.py)
-    spx = args.sweeps_per_exchange or (32 if (args.strong and world > 1) else k * round(64 / k))  # sweeps per halo exchange
-    sps = args.sweeps_per_step or 4 * spx                  # one step: ~1.6 ms at 4096^2
+    # sweeps per halo exchange (tools/slab_rate.py: a 4096^2 slab does 2.55e12 upd/s at 64, 2.71e12 at 96..128, 2.62e12 at 192:
+    # fewer launches and exchanges against taller tiles on the deep ghost rows; thin strong-scaling slabs: 32)
+    spx = args.sweeps_per_exchange or (32 if (args.strong and world > 1) else k * round(128 / k))
+    sps = args.sweeps_per_step or (4 * spx if (args.strong and world > 1) else 2 * spx)  # one step: 256 sweeps, ~1.5 ms at 4096^2
     if world > 1 and sps % spx:
         raise SystemExit("--sweeps-per-step must be a multiple of --sweeps-per-exchange")
 
