@@ -8,9 +8,12 @@ for case in range(int(os.environ.get("FUZZ_CASES", "60"))):
     rows = random.choice([96, 128, 192, 256, 320, 512, 1024, 2048, 3072])
     cols = random.choice([288, 320, 512, 544, 768, 1024, 1536, 2048, 4096])
     periodic = random.random() < 0.6
+    if os.environ.get("FUZZ_NARROW"):  # lattices narrower than a tile (a tile is a window on the periodic extension), few rows
+        rows = random.choice([64, 66, 96, 100, 128, 200, 256, 500, 1000, 2048])
+        cols = random.choice([128, 144, 160, 176, 192, 208, 224, 240, 256, 272, 288, 304])
     if not periodic and random.random() < 0.6:  # open lattices: any width / height
-        cols = random.randint(288, 2100)
-        rows = random.randint(96, 1100)
+        cols = random.randint(130, 400) if os.environ.get("FUZZ_NARROW") else random.randint(288, 2100)
+        rows = random.randint(64, 1100)
     if periodic and (rows % 2 or cols % 2):
         continue
     k = random.choice([0, 1, 3, 5, 8])

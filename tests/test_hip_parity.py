@@ -67,7 +67,8 @@ def test_ising2d_sweep_bit_exact(hip, rows, cols, periodic, kernel):
 
 
 TILED_LATTICES = [(96, 544), (128, 1024), (130, 560), (200, 2080), (256, 4096),
-                  (96, 288), (128, 320), (256, 512), (1024, 1024)]  # narrower lattices: 256-column tiles
+                  (96, 288), (128, 320), (256, 512), (1024, 1024),  # narrower lattices: 256-column tiles
+                  (200, 128), (66, 160), (256, 144)]  # narrower than a tile: the tile is a window on the periodic extension
 
 
 @pytest.mark.parametrize("periodic", [True, False])
