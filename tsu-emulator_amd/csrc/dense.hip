@@ -403,7 +403,7 @@ static hipError_t k2w_launch_replicas(const tsu_dense* d, int m, hipStream_t str
 struct K2wgList {
     int j[K2WG_MAX_N + 64];  // padded with (site 0, value 0) up to the next multiple of 64 entries
     int d[K2WG_MAX_N + 64];
-    int wcount[16];
+    alignas(16) int wcount[16];  // list entries per wave (0 for waves the workgroup does not have)
 };
 
 // every thread calls it; sites with pred set are listed in ascending order with their value; returns the list length
@@ -411,12 +411,21 @@ static __device__ __forceinline__ int k2wg_build(K2wgList& L, bool pred, int val
     const unsigned long long b = __ballot(pred);
     if (lane == 0) L.wcount[wave] = __popcll(b);
     __syncthreads();
-    int before = 0, total = 0;
-    for (int w = 0; w < nwaves; ++w) {
-        const int c = L.wcount[w];
-        before += w < wave ? c : 0;
-        total += c;
+    // all sixteen counts with four 16-byte LDS reads (waves that do not exist keep their 0): a loop up to nwaves paid
+    // one LDS latency per wave
+    int wc[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int4 v = reinterpret_cast<const int4*>(L.wcount)[q];
+        wc[4 * q] = v.x; wc[4 * q + 1] = v.y; wc[4 * q + 2] = v.z; wc[4 * q + 3] = v.w;
     }
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        before += w < wave ? wc[w] : 0;
+        total += wc[w];
+    }
+    (void)nwaves;
     if (pred) {
         const int at = before + __popcll(b & ((1ull << lane) - 1ull));
         L.j[at] = site;
@@ -495,6 +504,8 @@ __global__ __launch_bounds__(1024) void k2_wg(const TJ* __restrict__ JTp, const 
     // temps: one temperature per sweep (an annealing schedule) or NULL; reps: workgroup r sweeps state r of a tempering
     // ladder at its own temperature with its own stream (its uniforms follow those of replica r - 1)
     __shared__ K2wgList L;
+    if (threadIdx.x < 16) L.wcount[threadIdx.x] = 0;
+    __syncthreads();
     if (reps) {
         const K2Replica rp = reps[blockIdx.x];
         T = rp.T;
