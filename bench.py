@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- the contract benchmark: spin-updates/s of the checkerboard Gibbs sweep on an L x L Ising lattice.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--L 4096] [--sweeps-per-step 64] [--sweeps-per-launch 4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--L 4096] [--sweeps-per-step 256] [--sweeps-per-launch 8]
 
 N = 1: BASELINE.json configs[1] (IsingModel2D 4096 x 4096 at T_c, periodic, physical bias mode) on one MI355X.
 N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- every rank owns an L x L row slab of a
@@ -15,6 +15,10 @@ import json
 import os
 import sys
 import time
+
+# dmabuf IPC (the host driver of this pool supports nothing else): RCCL's cross-process buffers need it; exported by the
+# image already, kept here for environments built by hand
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tsu-emulator_amd"))
