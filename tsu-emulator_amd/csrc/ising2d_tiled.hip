@@ -899,9 +899,8 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
                 P.r.wrap_y = L->wrap_rows ? 1 : 0;
                 P.r.wrap_x = L->periodic ? 1 : 0;
                 P.r.xbuf = L->d_xbuf;
-                if (L->xsig != xsig || L->xgen + (uint32_t)((chunk + kmax - 1) / kmax) + 2u >= 16383u) {
-                    // the numbering restarts (or another strip layout starts): no element may look like one of the new run
-                    TSU_HIP_TRY(ctx, hipMemsetAsync(L->d_xbuf, 0, L->xbuf_cap * sizeof(uint64_t), ctx->stream));
+                const bool renumber = L->xsig != xsig || L->xgen + (uint32_t)((chunk + kmax - 1) / kmax) + 2u >= 16383u;
+                if (renumber) {
                     L->xsig = xsig;
                     L->xgen = 0;
                 }
@@ -924,6 +923,9 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
                     const int rcx = tsu_grid_exclusive_begin(ctx);
                     if (rcx != TSU_OK) return rcx;
                 }
+                // the numbering restarts (or another strip layout starts): no element may look like one of the new run
+                // (after the chaining above: an earlier launch of this lattice on another stream has finished with the buffer)
+                if (renumber) TSU_HIP_TRY(ctx, hipMemsetAsync(L->d_xbuf, 0, L->xbuf_cap * sizeof(uint64_t), ctx->stream));
                 hipLaunchKernelGGL(res_kern, dim3((unsigned)ntiles), dim3((unsigned)tv.threads), lds_bytes, ctx->stream, P);
                 L->launches += 1;
                 L->cur ^= 1;
