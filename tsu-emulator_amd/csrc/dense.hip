@@ -395,8 +395,8 @@ static hipError_t k2w_launch_replicas(const tsu_dense* d, int m, hipStream_t str
 // exact from iteration k on; about a dozen iterations in practice): every iteration lists the sites whose decision
 // changed (ascending, so floating-point sums do not depend on timing) and every thread adds their column entries with
 // j < i to its correction.  The flips are then added to every field (fields are handed from sweep to sweep and
-// recomputed from scratch every K2WG_REFRESH sweeps).  An iteration costs three workgroup barriers instead of a grid
-// barrier: n = 256 14 us per sweep against 43 us on the grid-wide path, n = 448 27 us against 46 us.
+// recomputed from scratch every K2WG_REFRESH sweeps).  An iteration costs two workgroup barriers and an L2 round trip instead
+// of a grid barrier: n = 256 14 us per sweep against 43 us on the grid-wide path, n = 448 27 us against 46 us.
 #define K2WG_MAX_N 1024
 #define K2WG_REFRESH 64
 
@@ -407,11 +407,11 @@ struct K2wgList {
 };
 
 // every thread calls it; sites with pred set are listed in ascending order with their value; returns the list length
-static __device__ __forceinline__ int k2wg_build(K2wgList& L, bool pred, int value, int site, int wave, int lane, int nwaves) {
+static __device__ __forceinline__ int k2wg_build(K2wgList& L, bool pred, int value, int site, int wave, int lane) {
     const unsigned long long b = __ballot(pred);
     if (lane == 0) L.wcount[wave] = __popcll(b);
     __syncthreads();
-    // all sixteen counts with four 16-byte LDS reads (waves that do not exist keep their 0): a loop up to nwaves paid
+    // all sixteen counts with four 16-byte LDS reads (waves that do not exist keep their 0): a loop over the waves paid
     // one LDS latency per wave
     int wc[16];
 #pragma unroll
@@ -425,7 +425,6 @@ static __device__ __forceinline__ int k2wg_build(K2wgList& L, bool pred, int val
         before += w < wave ? wc[w] : 0;
         total += wc[w];
     }
-    (void)nwaves;
     if (pred) {
         const int at = before + __popcll(b & ((1ull << lane) - 1ull));
         L.j[at] = site;
@@ -517,7 +516,7 @@ __global__ __launch_bounds__(1024) void k2_wg(const TJ* __restrict__ JTp, const 
         if (uniforms) uniforms += (size_t)blockIdx.x * n_burnin * n;
     }
     const __amdgpu_buffer_rsrc_t JT = __builtin_amdgcn_make_buffer_rsrc(const_cast<TJ*>(JTp), 0, n * n * (int)sizeof(TJ), 0x00020000);
-    const int i = threadIdx.x, lane = i & 63, wave = i >> 6, nwaves = blockDim.x >> 6;
+    const int i = threadIdx.x, lane = i & 63, wave = i >> 6;
     const bool on = i < n;
     const double b = (on && bias) ? bias[i] : 0.0;
     double invT = 1.0 / T;
@@ -532,7 +531,7 @@ __global__ __launch_bounds__(1024) void k2_wg(const TJ* __restrict__ JTp, const 
             invT = 1.0 / T;
         }
         if (sw % K2WG_REFRESH == 0) {  // fields from scratch: b + sum over the sites that are up of their column
-            const int cnt = k2wg_build(L, on && bit != 0, 1, i, wave, lane, nwaves);
+            const int cnt = k2wg_build(L, on && bit != 0, 1, i, wave, lane);
             f = k2wg_apply<TJ, false>(JT, L, cnt, n, i, lane, on, b);
         }
         double u = 0.5;
@@ -543,7 +542,7 @@ __global__ __launch_bounds__(1024) void k2_wg(const TJ* __restrict__ JTp, const 
         int iter = 0;
         for (; iter < n + 2; ++iter) {
             const int d_new = on ? k2w_decide(f + corr, u, lg, T, invT) - bit : 0;
-            const int cnt = k2wg_build(L, d_new != d_prev, d_new - d_prev, i, wave, lane, nwaves);
+            const int cnt = k2wg_build(L, d_new != d_prev, d_new - d_prev, i, wave, lane);
             if (cnt == 0) break;
             d_prev = d_new;
             corr = k2wg_apply<TJ, true>(JT, L, cnt, n, i, lane, on, corr);
@@ -556,7 +555,7 @@ __global__ __launch_bounds__(1024) void k2_wg(const TJ* __restrict__ JTp, const 
             next_record += n_per_sample;
         }
         if (sw + 1 < n_sweeps && (sw + 1) % K2WG_REFRESH != 0) {  // hand the fields on: every flip, every row
-            const int cnt = k2wg_build(L, d_prev != 0, d_prev, i, wave, lane, nwaves);
+            const int cnt = k2wg_build(L, d_prev != 0, d_prev, i, wave, lane);
             f = k2wg_apply<TJ, false>(JT, L, cnt, n, i, lane, on, f);
         }
     }
