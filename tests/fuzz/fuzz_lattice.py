@@ -14,6 +14,9 @@ for case in range(int(os.environ.get("FUZZ_CASES", "60"))):
     if not periodic and random.random() < 0.6:  # open lattices: any width / height
         cols = random.randint(130, 400) if os.environ.get("FUZZ_NARROW") else random.randint(288, 2100)
         rows = random.randint(64, 1100)
+    if periodic and os.environ.get("FUZZ_RAGGED"):  # periodic lattices of any even width / height: the wrap falls inside an octet
+        cols = 2 * random.randint(65, 1100)
+        rows = 2 * random.randint(32, 600)
     if periodic and (rows % 2 or cols % 2):
         continue
     k = random.choice([0, 1, 3, 5, 8])

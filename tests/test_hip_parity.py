@@ -124,6 +124,34 @@ def test_ising2d_tiled_open_lattice_of_any_width(hip, rows, cols, spl):
         lat.close()
 
 
+@pytest.mark.parametrize("rows,cols,spl", [(130, 300, 3), (96, 290, 8), (128, 1000, 5), (256, 1000, 8), (200, 130, 8), (64, 258, 2),
+                                           (1000, 1000, 0), (512, 2042, 0), (256, 1016, 0)])
+def test_ising2d_tiled_periodic_lattice_of_any_even_width(hip, rows, cols, spl):
+    """Periodic lattices whose width is not a multiple of 16 (IsingModel2D(1000)): the wrap falls inside the last octet of a
+    row; the workgroups whose window holds it take the one byte that crosses over from / to position v - 1 instead of 7.
+    Tiled kernel (also tile-resident: 1016 columns = 64 chunks) == oracle, including the tie path (coarse table)."""
+    seed = 57 + rows + cols
+    s0 = ora.ising2d_randomize(rows, cols, seed)
+    tables = [ora.ising2d_thresholds(1.0, 0.1, 2.0, hip.MODE_PHYSICAL),
+              np.array([(k * 0x0A3D) << 16 | 0x8000 for k in range(25)], dtype=np.uint64)]
+    for table in tables:
+        lat = hip.Lattice(rows, cols, True)
+        if spl:
+            lat.set_kernel(hip.KERNEL_TILED, spl)
+        lat.set_spins(s0)
+        lat.set_thresholds(table)
+        n0 = lat.launch_count()
+        lat.sweep(19, seed, sweep0=2)
+        assert lat.launch_count() - n0 <= -(-19 // (spl or 8))  # the tiled kernel, also when the library chooses (generic: 38 launches)
+        want = ora.ising2d_sweep(s0, True, table, 19, seed, sweep0=2)
+        np.testing.assert_array_equal(lat.get_spins(), want)
+        assert lat.observables() == ora.ising2d_observables(want, True)
+        lat.set_kernel(hip.KERNEL_GENERIC)  # pad bytes intact: the generic kernel reads whole chunks
+        lat.sweep(2, seed, sweep0=21)
+        np.testing.assert_array_equal(lat.get_spins(), ora.ising2d_sweep(want, True, table, 2, seed, sweep0=21))
+        lat.close()
+
+
 @pytest.mark.parametrize("rows,cols,periodic", [(32, 32, True), (4, 16, True), (128, 128, True), (64, 256, True), (30, 48, True), (4, 4, True), (8, 8, True), (20, 20, True), (50, 50, True), (126, 110, True),
                                                
                                                 (2, 2, False), (3, 2, False), (50, 50, False), (96, 160, False), (127, 113, False),
@@ -173,7 +201,7 @@ def test_ising2d_tiled_ties_and_clamps(hip):
 
 @pytest.mark.parametrize("nslab,ghost,k,spl", [(2, 8, 4, 0), (3, 16, 8, 0), (2, 2, 1, 0), (2, 32, 16, 4), (2, 40, 19, 8),
                                                 (3, 24, 12, 5)])
-@pytest.mark.parametrize("periodic,cols", [(True, 576), (False, 576), (True, 1024)])
+@pytest.mark.parametrize("periodic,cols", [(True, 576), (False, 576), (True, 1024), (True, 1000), (False, 1001)])
 def test_ising2d_tiled_slabs(hip, nslab, ghost, k, spl, periodic, cols):
     """Row slabs driven through the tiled kernel (ghost rows as the vertical halo) == whole lattice; with
     k > sweeps-per-launch a slab sweeps several launches per ghost refresh, extending into its ghost rows.

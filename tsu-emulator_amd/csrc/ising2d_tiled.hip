@@ -25,8 +25,9 @@ struct TiledParams {
     const int8_t* src;  // owned row 0 of the source buffer
     int8_t* dst;        // owned row 0 of the destination buffer
     long long pitch;
-    int rows, nchunks;           // owned rows; ceil(cols / 16) (a ragged last chunk only on open lattices)
+    int rows, nchunks;           // owned rows; ceil(cols / 16) (the last chunk may be ragged)
     int cols;
+    int q_shift;                 // first octet of tile column 0 (periodic lattices of ragged width: keeps the ragged octet out of every halo)
     int tile_h;                  // tile height of this launch (even; the template H is the default and the LDS budget)
     int r_begin, r_end;          // rows this launch computes: [0, rows) or, for a slab that will sweep again before its
                                  // next ghost refresh, [-ext, rows + ext) so that its own halo stays exact
@@ -135,6 +136,7 @@ struct Rows2Ctx {
     uint32_t r_par, r_slot;           // open lattices: column parity of the last column and its site within the octet
     uint32_t rm_lo, rm_hi;            // 0xFF at that site's byte
     uint64_t vm_e, vm_o;              // open lattices: 0x01 for the even / odd columns of this octet that exist
+    int sh_next, sh_prev;             // periodic lattices of ragged width (SEAM): where the wrap meets this octet, see sweep_pairs
 };
 
 // thresholds for the 8 sites of one octet given their up-counts, compared with one Philox block: d < 0 = accept
@@ -190,7 +192,7 @@ static __device__ __forceinline__ uint64_t pack_flags(const u32x4& d) {
 }
 
 // P0 = column parity of the updated colour in row tr_lo (and 1-P0 in the row below it)
-template <int NO, int P0, bool EDGE, bool OPEN>
+template <int NO, int P0, bool EDGE, bool OPEN, bool SEAM = false>
 static __device__ __forceinline__ void sweep_pairs(const Rows2Ctx& c, const PhiloxKeys& K, int al, int oct, uint32_t cq, int RL) {
     // One byte offset into the source plane and one row counter are the only induction variables (kept opaque so
     // that the compiler does not re-derive them from a separate trip counter); everything else is an immediate.
@@ -208,8 +210,14 @@ static __device__ __forceinline__ void sweep_pairs(const Rows2Ctx& c, const Phil
         const char* ps = ps0 + off;
         const uint64_t R0 = *reinterpret_cast<const uint64_t*>(ps - NO * 8), R1 = *reinterpret_cast<const uint64_t*>(ps);
         const uint64_t R2 = *reinterpret_cast<const uint64_t*>(ps + NO * 8), R3 = *reinterpret_cast<const uint64_t*>(ps + 2 * NO * 8);
-        const uint32_t A0 = *reinterpret_cast<const uint32_t*>(ps + (P0 ? 8 : -4));
-        const uint32_t A1 = *reinterpret_cast<const uint32_t*>(ps + NO * 8 + (P0 ? -4 : 8));
+        const uint32_t A0 = SEAM ? 0u : *reinterpret_cast<const uint32_t*>(ps + (P0 ? 8 : -4));
+        const uint32_t A1 = SEAM ? 0u : *reinterpret_cast<const uint32_t*>(ps + NO * 8 + (P0 ? -4 : 8));
+        // SEAM (a periodic lattice whose width is not a multiple of 16, workgroups whose window holds the wrap): the last
+        // octet of a row has only v sites per colour, so the site after its last one is site 0 of octet 0, and the site
+        // before site 0 of octet 0 is that last one: the whole neighbouring octet is read and the one byte that crosses
+        // over is taken from / put at position v - 1 instead of 7 (sh_next / sh_prev; 56 for every other octet)
+        const uint64_t Na = SEAM ? *reinterpret_cast<const uint64_t*>(ps + (P0 ? 8 : -8)) : 0ull;
+        const uint64_t Nb = SEAM ? *reinterpret_cast<const uint64_t*>(ps + NO * 8 + (P0 ? -8 : 8)) : 0ull;
         __builtin_amdgcn_sched_barrier(0);  // the reads stay above the Philox blocks ...
         int rga = rg, rgb = rg + 1;
         if (EDGE) {
@@ -221,10 +229,18 @@ static __device__ __forceinline__ void sweep_pairs(const Rows2Ctx& c, const Phil
         __builtin_amdgcn_sched_barrier(0);  // ... and their first use stays below
         const uint32_t C0l = (uint32_t)R1, C0h = (uint32_t)(R1 >> 32), C1l = (uint32_t)R2, C1h = (uint32_t)(R2 >> 32);
         // horizontal neighbours: compact bytes (j, j+1) when the parity is 1, (j-1, j) when it is 0
-        const uint32_t S0l = P0 ? __builtin_amdgcn_alignbyte(C0h, C0l, 1) : __builtin_amdgcn_alignbyte(C0l, A0, 3);
-        const uint32_t S0h = P0 ? __builtin_amdgcn_alignbyte(A0, C0h, 1) : __builtin_amdgcn_alignbyte(C0h, C0l, 3);
-        const uint32_t S1l = P0 ? __builtin_amdgcn_alignbyte(C1l, A1, 3) : __builtin_amdgcn_alignbyte(C1h, C1l, 1);
-        const uint32_t S1h = P0 ? __builtin_amdgcn_alignbyte(C1h, C1l, 3) : __builtin_amdgcn_alignbyte(A1, C1h, 1);
+        uint32_t S0l = P0 ? __builtin_amdgcn_alignbyte(C0h, C0l, 1) : __builtin_amdgcn_alignbyte(C0l, A0, 3);
+        uint32_t S0h = P0 ? __builtin_amdgcn_alignbyte(A0, C0h, 1) : __builtin_amdgcn_alignbyte(C0h, C0l, 3);
+        uint32_t S1l = P0 ? __builtin_amdgcn_alignbyte(C1l, A1, 3) : __builtin_amdgcn_alignbyte(C1h, C1l, 1);
+        uint32_t S1h = P0 ? __builtin_amdgcn_alignbyte(C1h, C1l, 3) : __builtin_amdgcn_alignbyte(A1, C1h, 1);
+        if (SEAM) {
+            const uint64_t nxa = (Na & 0xFFull) << c.sh_next, pva = (Na >> c.sh_prev) & 0xFFull;
+            const uint64_t nxb = (Nb & 0xFFull) << c.sh_next, pvb = (Nb >> c.sh_prev) & 0xFFull;
+            const uint64_t Sa = P0 ? ((R1 >> 8) | nxa) : ((R1 << 8) | pva);
+            const uint64_t Sb = P0 ? ((R2 << 8) | pvb) : ((R2 >> 8) | nxb);
+            S0l = (uint32_t)Sa; S0h = (uint32_t)(Sa >> 32);
+            S1l = (uint32_t)Sb; S1h = (uint32_t)(Sb >> 32);
+        }
         // R1 + R2 is shared by both rows' vertical+centre sums
         const uint32_t ml = C0l + C1l, mh = C0h + C1h;
         const uint32_t cnt0l = (uint32_t)R0 + ml + S0l, cnt0h = (uint32_t)(R0 >> 32) + mh + S0h;
@@ -254,6 +270,10 @@ static __device__ __forceinline__ void sweep_pairs(const Rows2Ctx& c, const Phil
         if (OPEN) {  // what lies beyond the open edge stays empty (it is a neighbour of the edge sites in the next half-sweep)
             n0 = (rga < 0 || rga > c.last_row) ? 0 : (n0 & (P0 ? c.vm_o : c.vm_e));
             n1 = (rgb < 0 || rgb > c.last_row) ? 0 : (n1 & (P0 ? c.vm_e : c.vm_o));
+        }
+        if (SEAM) {  // the sites the last octet does not have stay empty
+            n0 &= c.vm_e;
+            n1 &= c.vm_e;
         }
         *reinterpret_cast<uint64_t*>(pd) = n0;
         *reinterpret_cast<uint64_t*>(pd + NO * 8) = n1;
@@ -304,7 +324,7 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
     const int tid = threadIdx.x;
     if (tid < 25) s_thr[tid] = p.thr[tid];
 
-    const int q0 = tx * WO, r0 = p.r_begin + ty * H, Rb = r0 - 2 * k;
+    const int q0 = tx * WO + p.q_shift, r0 = p.r_begin + ty * H, Rb = r0 - 2 * k;
 
     // a thread owns one octet column (al = row lane, oct = column) in all three phases: no div/mod in any loop
     const int al = tid / NO, oct = tid - al * NO;
@@ -318,7 +338,7 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
     }
     const uint32_t cq = (uint32_t)cqi;
     // open lattices of ragged width: the columns of this thread's chunk that exist (all 16, fewer in the last chunk, none outside)
-    int nv = OPEN ? p.cols - 16 * cqi : 16;
+    int nv = p.cols - 16 * cqi;  // (cqi: the octet's own index in the lattice, wrapped for a periodic one)
     if (col_out) nv = 0;
     if (nv > 16) nv = 16;
     auto first_sites = [](int n) { return n >= 8 ? 0x0101010101010101ull : (((1ull << (8 * n)) - 1) & 0x0101010101010101ull); };
@@ -352,6 +372,8 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
                     if (OPEN) {
                         const long long grow = p.row0 + Rb + tr;
                         if (grow < 0 || grow >= p.total_rows) ev = od = 0;  // beyond the open edge: nothing there
+                    }
+                    if (OPEN || nv < 16) {  // the pad bytes of a ragged last chunk are 0, which would read as "up"
                         ev &= vm_e;
                         od &= vm_o;
                     }
@@ -387,6 +409,15 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
     c.rm_hi = c.r_slot < 4 ? 0u : 0xFFu << (8 * (c.r_slot - 4));
     c.vm_e = vm_e;
     c.vm_o = vm_o;
+    // periodic lattice of ragged width: v sites per colour in the last octet of a row (cols is even: the same for both)
+    const int v_last = (p.cols >> 1) & 7;
+    const bool ragged = !OPEN && v_last != 0;
+    c.sh_next = (ragged && cqi == p.nchunks - 1) ? 8 * (v_last - 1) : 56;
+    c.sh_prev = (ragged && cqi == 0) ? 8 * (v_last - 1) : 56;
+    // does this workgroup's window (octets q0 - 1 .. q0 + WO of the periodic extension) hold the ragged octet or octet 0?
+    int w0 = (q0 - 1) % p.nchunks;
+    if (w0 < 0) w0 += p.nchunks;
+    const bool seam = ragged && (w0 == 0 || w0 + NO - 1 >= p.nchunks - 1);
     asm volatile("v_mov_b32 %0, %1" : "=v"(c.tblH0) : "s"(p.tblH0));
     asm volatile("v_mov_b32 %0, %1" : "=v"(c.tblH1) : "s"(p.tblH1));
     asm volatile("v_mov_b32 %0, %1" : "=v"(c.tblL0) : "s"(p.tblL0));
@@ -425,6 +456,9 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
             if (OPEN) {
                 if (par0) sweep_pairs<NO, 1, false, true>(c, K, al, oct, cq, RL);
                 else sweep_pairs<NO, 0, false, true>(c, K, al, oct, cq, RL);
+            } else if (seam) {
+                if (par0) sweep_pairs<NO, 1, true, false, true>(c, K, al, oct, cq, RL);
+                else sweep_pairs<NO, 0, true, false, true>(c, K, al, oct, cq, RL);
             } else if (edge) {
                 if (par0) sweep_pairs<NO, 1, true, false>(c, K, al, oct, cq, RL);
                 else sweep_pairs<NO, 0, true, false>(c, K, al, oct, cq, RL);
@@ -562,8 +596,8 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
         for (int q = 0; q < 4; ++q) R->dbg[q] = tl[q];
 #undef RES_MARK
     // interior octets are tile columns 1 .. NO-2: the same thread -> column mapping, halo columns idle
-    if (p.debug < 2 && al < RLMAX && oct >= 1 && oct <= WO && q0 + oct - 1 < p.nchunks) {
-        int8_t* col = dst + 16 * (long long)(q0 + oct - 1);
+    if (p.debug < 2 && al < RLMAX && oct >= 1 && oct <= WO && q0 + oct - 1 < p.nchunks + p.q_shift) {
+        int8_t* col = dst + 16 * (long long)cqi;  // (= q0 + oct - 1, wrapped when the tiling starts at octet q_shift)
         int gpar = (int)((p.row0 + r0 + al) & 1);
 #pragma unroll 2
         for (int hr = al; hr < H; hr += RLMAX) {
@@ -576,7 +610,7 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
                 const uint32_t o0 = perm(0u, 0x000001FFu, (uint32_t)od), o1 = perm(0u, 0x000001FFu, (uint32_t)(od >> 32));
                 uint4 v = make_uint4(perm(o0, e0, 0x05010400u), perm(o0, e0, 0x07030602u), perm(o1, e1, 0x05010400u),
                                      perm(o1, e1, 0x07030602u));
-                if (OPEN && nv < 16) {  // ragged last chunk: the pad bytes of the row stay 0
+                if (nv < 16) {  // ragged last chunk: the pad bytes of the row stay 0
                     auto bytes = [](int n) { return n >= 4 ? 0xFFFFFFFFu : (n <= 0 ? 0u : (1u << (8 * n)) - 1u); };
                     v.x &= bytes(nv);
                     v.y &= bytes(nv - 4);
@@ -660,6 +694,25 @@ const TileVariant kVariants[] = {
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
+// A periodic lattice whose width is not a multiple of 16 has a ragged last octet (v < 8 sites per colour).  As a halo
+// octet it would give a tile 2v columns of history instead of 16, so the tiling starts at octet `shift` such that the
+// ragged octet is never the left halo of a tile (tile start = 0 mod nch) nor the right halo of any but the last tile.
+// 0: not needed; -1: no such start (the generic kernel takes the lattice).
+int ragged_shift(const tsu_ising2d* L, int WO) {
+    if (!L->periodic || L->cols % 16 == 0) return 0;
+    const int nch = (L->cols + 15) / 16, tiles_x = (nch + WO - 1) / WO;
+    for (int shift = 1; shift < WO && shift < nch - 1; ++shift) {
+        bool ok = true;
+        for (int t = 0; t < tiles_x && ok; ++t) {
+            const int s = t * WO + shift;
+            if (s % nch == 0) ok = false;
+            if (t < tiles_x - 1 && (s + WO) % nch == nch - 1) ok = false;
+        }
+        if (ok) return shift;
+    }
+    return -1;
+}
+
 int pick_variant(const tsu_ising2d* L) {
     static int env = -2;
     if (env == -2) {
@@ -693,7 +746,7 @@ int pick_variant(const tsu_ising2d* L) {
         for (int ci = 0; whole && ci < (int)(sizeof(cand) / sizeof(cand[0])); ++ci) {
             const TileVariant& c = kVariants[cand[ci]];
             if (!(L->periodic ? c.kernel : c.open)) continue;
-            if (2 * nch < c.WO || L->total_rows < c.H + 4 * KMAX) continue;
+            if (2 * nch < c.WO || L->total_rows < c.H + 4 * KMAX || ragged_shift(L, c.WO) < 0) continue;
             const long long nt = (long long)((L->rows + c.H - 1) / c.H) * ((nch + c.WO - 1) / c.WO);
             if (nt > cus) continue;
             const bool resident = (L->periodic ? c.resident : c.resident_open) && L->rows % c.H == 0 && nch % c.WO == 0;
@@ -708,7 +761,8 @@ int pick_variant(const tsu_ising2d* L) {
     // a variant must fit the lattice (a tile is a window on the lattice's periodic extension: its octet and row indices
     // wrap at most twice / once) and, for an open lattice, have the OPEN form built; -1 = none does (generic kernel)
     auto fits = [&](int vv) {
-        return 2 * ((L->cols + 15) / 16) >= kVariants[vv].WO && L->total_rows >= kVariants[vv].H + 4 * KMAX && (L->periodic || kVariants[vv].open);
+        return 2 * ((L->cols + 15) / 16) >= kVariants[vv].WO && L->total_rows >= kVariants[vv].H + 4 * KMAX && (L->periodic || kVariants[vv].open) &&
+               ragged_shift(L, kVariants[vv].WO) >= 0;
     };
     if (!fits(v)) {
         static const int fallback[] = {6, 26, 27};
@@ -724,7 +778,6 @@ int pick_variant(const tsu_ising2d* L) {
 }  // namespace
 
 int tsu_ising2d_tiled_supported(const tsu_ising2d* L) {
-    if (L->cols % 16 != 0 && L->periodic) return 0;           // the wrap must not fall inside an octet (open lattices: any width)
     if (pick_variant(L) < 0) return 0;                        // no tile shape fits (too narrow / too few rows): generic kernel
     const bool open_whole = !L->periodic && L->ghost == 0 && L->total_rows == L->rows;  // beyond its edges: nothing
     if (!L->wrap_rows && !open_whole && L->ghost < 2) return 0;
@@ -778,6 +831,7 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
     p.wrap_rows = L->wrap_rows;
     p.ghost = L->ghost;
     p.tiles_x = (p.nchunks + TILE_WO - 1) / TILE_WO;
+    p.q_shift = ragged_shift(L, TILE_WO);
     {
         static int dbg = -1;
         if (dbg < 0) {
