@@ -8,7 +8,9 @@ random.seed(int(os.environ.get("FUZZ_SEED", "3")))
 for case in range(int(os.environ.get("FUZZ_CASES", "30"))):
     rows = random.choice([256, 512, 1024, 2048, 4096])
     cols = random.choice([512, 544, 1024, 2048, 4096])
-    S = random.choice([4, 8, 16, 24, 32, 64])
+    if os.environ.get("FUZZ_RAGGED"):  # widths that are not a multiple of 16 (the wrap falls inside an octet), also resident ones
+        cols = random.choice([290, 500, 1000, 1016, 1500, 2040, 3000])
+    S = random.choice([4, 8, 16, 24, 32, 64, 128])
     k = random.choice([0, 4, 5, 8])
     if 2 * S > rows:
         continue
