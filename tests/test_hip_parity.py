@@ -125,7 +125,8 @@ def test_ising2d_tiled_open_lattice_of_any_width(hip, rows, cols, spl):
 
 
 @pytest.mark.parametrize("rows,cols,spl", [(130, 300, 3), (96, 290, 8), (128, 1000, 5), (256, 1000, 8), (200, 130, 8), (64, 258, 2),
-                                           (1000, 1000, 0), (512, 2042, 0), (256, 1016, 0)])
+                                           (1000, 1000, 0), (512, 2042, 0), (256, 1016, 0),
+                                           (128, 520, 8), (96, 264, 8), (128, 1032, 8), (192, 530, 0)])  # 33 / 17 / 65 / 34 chunks: tiling origins 1 and 2
 def test_ising2d_tiled_periodic_lattice_of_any_even_width(hip, rows, cols, spl):
     """Periodic lattices whose width is not a multiple of 16 (IsingModel2D(1000)): the wrap falls inside the last octet of a
     row; the workgroups whose window holds it take the one byte that crosses over from / to position v - 1 instead of 7.
