@@ -1,4 +1,4 @@
-"""Soak of the tile-resident kernel's flag protocol: N generations in few launches == the same sweeps issued as one
+"""Soak of the tile-resident kernel's strip exchange: N generations in few launches == the same sweeps issued as one
 8-sweep launch per call (never resident).  usage: soak_resident.py [L] [sweeps]"""
 import os, sys, time, zlib
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tsu-emulator_amd"))
