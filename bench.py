@@ -327,6 +327,8 @@ def main():
                 extra[f"ising2d_L{L2}"] = time_lattice(hip, ctx, L2, k2, 120)
             # BASELINE configs[0], the reference's own CPU-runnable case (cpu_reference_order times its loop on the same lattice)
             extra["ising2d_32x32"] = time_lattice(hip, ctx, 32, 0, 20000)
+            # a width that is not a multiple of 16 (the wrap falls inside an octet): IsingModel2D(1000)
+            extra["ising2d_1000x1000"] = time_lattice(hip, ctx, 1000, 0, 4096)
             extra["langevin_dim_2^20"] = time_langevin(hip, ctx)
             extra["dense_gibbs"] = time_dense(hip, ctx)
             out["extra"] = extra
