@@ -4,8 +4,10 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--L 4096] [--sweeps-per-step 256] [--sweeps-per-launch 8]
 
 N = 1: BASELINE.json configs[1] (IsingModel2D 4096 x 4096 at T_c, periodic, physical bias mode) on one MI355X.
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- every rank owns an L x L row slab of a
-(N*L) x L lattice, halo exchange by RCCL send/recv, no collective on the sweep path.
+N > 1 (one rank per GPU, started by torch.distributed.run -- by the caller, or by bench.py itself as a child process
+when it is run plainly as `python bench.py --gpus N`): weak scaling -- every rank owns an L x L row slab of a
+(N*L) x L lattice, halo exchange by RCCL send/recv, no collective on the sweep path.  `--strong --L 16384` is BASELINE
+configs[3] (ONE lattice cut into N slabs).  The run refuses to report a world different from --gpus.
 
 A step = `sweeps-per-step` full lattice sweeps (each sweep updates every spin once: colour 0, then colour 1).
 Inputs are resident in HBM before the timed region.  One JSON line is printed by rank 0.
@@ -156,7 +158,7 @@ def time_dense(hip, ctx, n=16384):
             "J_stream_GBps": n * n * 4 / (ms * 1e-3) / 1e9}
 
 
-def main():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -171,7 +173,52 @@ def main():
                          "instead of the default weak scaling (L x L per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
-    args = ap.parse_args()
+    return ap
+
+
+def launch_plan(gpus, env, argv, free_port=None):
+    """What `python bench.py --gpus N ...` does about its process layout, decided BEFORE torch or the GPU is touched.
+
+    * already inside a rank of a launcher (WORLD_SIZE set): run inline; the world must equal --gpus (checked in main),
+    * --gpus 1 and no launcher: run inline on one GPU,
+    * --gpus N > 1 and no launcher: spawn `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD
+      process (never an exec: a process that has initialised the GPU must not be replaced) and relay its output and
+      exit code.
+    Returns ("inline", None), ("spawn", command list) or ("error", message)."""
+    if gpus < 1:
+        return "error", f"--gpus must be >= 1, got {gpus}"
+    ws = env.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != gpus:
+            return "error", (f"bench.py --gpus {gpus} was started inside a launcher with WORLD_SIZE={ws}: refusing to "
+                             f"report n_gpus={ws} for a run asked to use {gpus}")
+        return "inline", None
+    if gpus == 1:
+        return "inline", None
+    port = free_port() if free_port else 29500
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return "spawn", cmd
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def main():
+    args = build_parser().parse_args()
+    mode, what = launch_plan(args.gpus, os.environ, sys.argv[1:], _free_port)
+    if mode == "error":
+        raise SystemExit("bench.py: " + what)
+    if mode == "spawn":
+        # one rank per GPU: the ranks are started by torch.distributed.run; this parent never imports torch or touches a GPU
+        import subprocess
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        proc = subprocess.run(what, env=env)
+        raise SystemExit(proc.returncode)
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -182,6 +229,9 @@ def main():
     # one rank per GPU; BENCH_BACKEND=gloo lets several ranks share a GPU (rehearsal of the N > 1 path on a 1-GPU box)
     backend = os.environ.get("BENCH_BACKEND", "nccl")
     if world > torch.cuda.device_count():
+        if backend == "nccl":
+            raise SystemExit(f"bench.py: --gpus {world} needs {world} GPUs, this node shows {torch.cuda.device_count()} "
+                             "(RCCL wants one GPU per rank; BENCH_BACKEND=gloo rehearses the path with ranks sharing a GPU)")
         # rehearsal with several ranks on one GPU: two processes' tile-resident grids cannot both be on the chip, and half of
         # each would wait for the other half for ever (reported as a timeout) -- one launch per generation there
         os.environ.setdefault("TSU_K1_RESIDENT", "0")
@@ -194,6 +244,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         else:
             dist.init_process_group(backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus asked for {args.gpus}")
 
     from tsu import _hip as hip
     from tsu.distributed import SlabLattice
@@ -297,7 +349,7 @@ def main():
             "value": value, "unit": "spin-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong" if (args.strong and world > 1) else "weak", "vs_baseline": None,
             "dtype": "int8", "data": "synthetic (Philox i.i.d. +-1 start, seed 42)",
-            "backend": backend if world > 1 else None,
+            "backend": backend if world > 1 else None, "ranks_seen": world, "gpus_requested": args.gpus,
             "config": {"workload": f"IsingModel2D {rows_local}x{L} per GPU at T_c=2.269185, J=1, h=0, periodic, checkerboard Gibbs sweep "
                                    "(BASELINE.json configs[1])", "L": L, "lattice_rows": rows_local * world, "lattice_cols": L,
                        "sweeps_per_step": sps, "sweeps_per_generation": k, "sweeps_per_launch": sweeps_per_launch_avg, "sweeps_per_exchange": spx if world > 1 else None,

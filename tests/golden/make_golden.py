@@ -10,7 +10,8 @@ The script imports the reference package from /root/reference (read-only), drive
 public entry points with seeded inputs, and stores ONLY arrays (inputs, the RNG draws the
 run consumed, and outputs) as .npz files.  No reference source text or bytecode is stored.
 
-Fixture ids follow SURVEY.md section 8(c): G1..G9.
+Fixture ids follow SURVEY.md section 8(c): G1..G9; G10 (equilibrium observables of the reference's own sampler at
+T = 2.0, T_c, 2.5 on 16 x 16 and 32 x 32 lattices, ~15 minutes on 7 cores) pins the acceptance criterion of BASELINE.json.
 """
 import os
 import sys
@@ -262,8 +263,88 @@ def g9():
     save("g9_distribution", **arrs)
 
 
+# ---------------------------------------------------------------- G10: equilibrium observables (acceptance criterion)
+T_C = 2.269185314213022
+
+
+def _g10_chain(job):
+    """One independent chain of the reference's own sampler (GibbsSampler.sample_boltzmann behind IsingGrid) on an
+    L x L periodic lattice: per-sweep |m|, m, m^2 and (every `estride` sweeps) e = E/N through IsingGrid.energy."""
+    L, T, mode, chain, burnin, n_sweeps, estride, nblocks = job
+    g = IsingGrid((L, L), J=1.0, config=IsingConfig(temperature=T, n_burnin=0, n_sweeps=1), periodic=True)
+    g.sampler.config.n_sweeps = 1
+    Jb = g._get_bit_coupling()
+    hb = g._get_bit_bias() if mode == "compat" else 2 * g.h - 2 * g.J.sum(axis=1)
+    np.random.seed(100000 + 1000 * L + 100 * int(T * 10) + 10 * (mode == "compat") + chain)
+    N = L * L
+    state = np.random.randint(0, 2, size=N)
+    state = g.sampler.sample_boltzmann(Jb, bias=hb, n_samples=1, burnin=burnin, initial_state=state)[-1]
+    chunk = 1000
+    m = np.empty(n_sweeps)
+    e = []
+    done = 0
+    while done < n_sweeps:
+        n = min(chunk, n_sweeps - done)
+        smp = g.sampler.sample_boltzmann(Jb, bias=hb, n_samples=n, burnin=0, initial_state=state)
+        state = smp[-1]
+        spins = g._bits_to_spins(smp)
+        m[done:done + n] = spins.sum(axis=1) / N
+        for i in range(0, n, estride):
+            e.append(g.energy(spins[i]) / N)
+        done += n
+    e = np.array(e)
+
+    def blocks(x):
+        nb = nblocks
+        x = x[:len(x) // nb * nb]
+        return x.reshape(nb, -1).mean(axis=1)
+    return (L, T, mode, chain, blocks(np.abs(m)), blocks(m), blocks(m * m), blocks(m ** 4), blocks(e), blocks(e * e))
+
+
+def g10():
+    """<|m|>, <m>, <m^2>, <m^4>, <e>, <e^2> with blocked standard errors for IsingGrid 16^2 and 32^2 (periodic, J=1, h=0)
+    at T = 2.0, T_c, 2.5 -- the reference's own sampler, shipped ("compat") bias and corrected ("physical") bias.
+    Independent chains on the container's cores; block means over all chains give mean and standard error."""
+    import multiprocessing as mp
+    jobs = []
+    nblocks = 20
+    for L in (16, 32):
+        for T in (2.0, T_C, 2.5):
+            for mode in ("compat", "physical"):
+                if mode == "compat":        # the shipped bias is a field of strength 2*J*deg: m ~ 1, decorrelates at once
+                    chains, burnin, n = 2, 200, (4000 if L == 16 else 2000)
+                elif abs(T - T_C) < 1e-6:
+                    chains, burnin, n = 14, (2000 if L == 16 else 5000), (200000 if L == 16 else 80000)
+                else:
+                    chains, burnin, n = 7, (1000 if L == 16 else 2000), (60000 if L == 16 else 20000)
+                estride = 1 if L == 16 else 8
+                for c in range(chains):
+                    jobs.append((L, T, mode, c, burnin, n, estride, nblocks))
+    jobs.sort(key=lambda j: -(j[0] ** 2) * j[5])
+    with mp.Pool(int(os.environ.get("G10_WORKERS", "7"))) as pool:
+        results = pool.map(_g10_chain, jobs, chunksize=1)
+    arrs = {"T_c": T_C}
+    cases = {}
+    for (L, T, mode, chain, am, m, m2, m4, e, e2) in results:
+        cases.setdefault((L, T, mode), []).append((am, m, m2, m4, e, e2))
+    for (L, T, mode), rs in sorted(cases.items()):
+        key = f"L{L}_T{T:.4f}_{mode}"
+        job = [j for j in jobs if j[:3] == (L, T, mode)][0]
+        arrs[key + "_chains"] = len(rs)
+        arrs[key + "_sweeps_per_chain"] = job[5]
+        arrs[key + "_burnin"] = job[4]
+        for idx, name in enumerate(("absm", "m", "m2", "m4", "e", "e2")):
+            b = np.concatenate([r[idx] for r in rs])      # block means of all chains
+            arrs[f"{key}_{name}_mean"] = b.mean()
+            arrs[f"{key}_{name}_se"] = b.std(ddof=1) / np.sqrt(len(b))
+            arrs[f"{key}_{name}_blocks"] = b
+        print(key, "<|m|> = %.5f +- %.5f   <e> = %.5f +- %.5f" % (arrs[key + "_absm_mean"], arrs[key + "_absm_se"],
+                                                                 arrs[key + "_e_mean"], arrs[key + "_e_se"]), flush=True)
+    save("g10_equilibrium", **arrs)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
-    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9):
+    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10):
         if not only or fn.__name__ in only:
             fn()

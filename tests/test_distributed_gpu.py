@@ -87,3 +87,83 @@ def test_two_ranks_sharing_one_gpu_over_gloo():
     want = ora.ising2d_sweep(ora.ising2d_randomize(256, 576, 9), True, table, 2 * k + 3, 9)
     np.testing.assert_array_equal(full, want)
     assert obs == ora.ising2d_observables(want, True)
+
+
+# ------------------------------------------------------------------ RCCL (backend "nccl")
+def _nccl_worker(rank, world, port, q, rows, cols, k, sweeps):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tsu-emulator_amd"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    from tsu import _hip
+    from tsu.distributed import SlabLattice
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                            device_id=torch.device(f"cuda:{rank}"))
+    try:
+        lat = SlabLattice(rows, cols, periodic=True, sweeps_per_exchange=k, seed=21, device=rank)
+        assert lat.backend == "nccl" and lat.distributed and not lat._host_staged
+        lat.randomize()
+        lat.set_model(1.0, 0.0, 2.269185, _hip.MODE_PHYSICAL)
+        lat.sweep(sweeps)
+        obs = lat.observables()          # all_reduce of a cuda tensor over RCCL
+        full = lat.gather_spins()        # gather of cuda tensors over RCCL
+        t = torch.ones(1, device=f"cuda:{rank}")
+        dist.all_reduce(t)
+        dist.barrier()
+        if rank == 0:
+            q.put((full, obs, float(t[0])))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_nccl(world, rows, cols, k, sweeps):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, world, port, q, rows, cols, k, sweeps)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full, obs, ones = q.get(timeout=300)
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert ones == world
+    table = ora.ising2d_thresholds(1.0, 0.0, 2.269185, 0)
+    want = ora.ising2d_sweep(ora.ising2d_randomize(world * rows, cols, 21), True, table, sweeps, 21)
+    np.testing.assert_array_equal(full, want)
+    assert obs == ora.ising2d_observables(want, True)
+
+
+def test_rccl_process_group_of_one_rank_runs_the_nccl_branches():
+    """init_process_group("nccl") + SlabLattice on the device halo path + all_reduce/gather of cuda tensors: everything
+    of the N > 1 path that one GPU can execute (the send/recv pair itself needs a second GPU: next test)."""
+    _run_nccl(1, 256, 1024, 8, 19)
+
+
+def test_rccl_two_ranks_send_recv_halo():
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    _run_nccl(2, 256, 1024, 8, 19)
+
+
+def test_bench_gpus_2_on_this_box_is_never_reported_as_one_gpu():
+    """`python bench.py --gpus 2` launches its own ranks; with a single GPU it must fail loudly, with two it must say 2."""
+    import json
+    import subprocess
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--ramp-steps", "1", "--no-cpu-baseline", "--no-extra"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0, r.stdout
+        assert '"n_gpus"' not in r.stdout
+        assert "needs 2 GPUs" in r.stderr
+    else:
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        out = json.loads(line)
+        assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["backend"] == "nccl"

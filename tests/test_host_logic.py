@@ -3,6 +3,7 @@ declares, and the product path fails loudly (no CPU fallback) when there is no G
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -228,3 +229,36 @@ def test_tsu_config_and_helpers(golden):
     assert r["passes_ks_test"] and r["n_samples"] == 4000
     r = validate_distribution((rng.random(2000) < 0.7).astype(int), "bernoulli", {"p": 0.7})
     assert r["passes_test"] and abs(r["empirical_prob"] - 0.7) < 0.05
+
+
+# ------------------------------------------------------------------ bench.py process layout (no GPU, no torch import)
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_launch_plan_spawns_one_rank_per_gpu():
+    b = _bench_module()
+    assert b.launch_plan(1, {}, []) == ("inline", None)
+    mode, cmd = b.launch_plan(4, {}, ["--gpus", "4", "--steps", "5"], free_port=lambda: 12345)
+    assert mode == "spawn"
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "12345"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "5"]
+    # inside a launcher: inline when the world is the one asked for, an error (never a silent n_gpus) otherwise
+    assert b.launch_plan(8, {"WORLD_SIZE": "8"}, []) == ("inline", None)
+    assert b.launch_plan(8, {"WORLD_SIZE": "1"}, [])[0] == "error"
+    assert b.launch_plan(1, {"WORLD_SIZE": "2"}, [])[0] == "error"
+    assert b.launch_plan(0, {}, [])[0] == "error"
+
+
+def test_bench_refuses_a_world_that_is_not_the_one_requested():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()

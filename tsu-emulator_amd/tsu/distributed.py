@@ -203,8 +203,10 @@ class SlabLattice:
         """(sum of spins, sum over bonds) of the WHOLE lattice: local reductions + one all-reduce of two int64."""
         self.exchange()  # the bond to the row below the slab needs a fresh ghost row
         s, b = self.lat.observables()
-        if self.world == 1:
+        if not self.distributed:
             return s, b
+        # with a process group the sums always go through the collective (a one-rank RCCL group included: the same code
+        # runs at every world size)
         t = self.torch.tensor([s, b], dtype=self.torch.int64)
         if self.backend == "nccl":
             t = t.cuda(self.device_index)
@@ -214,7 +216,7 @@ class SlabLattice:
     def gather_spins(self) -> Optional[np.ndarray]:
         """The whole lattice on rank 0 (tests / small lattices only)."""
         mine = self.torch.from_numpy(self.local_spins().copy())
-        if self.world == 1:
+        if not self.distributed:
             return mine.numpy()
         if self.backend == "nccl":
             mine = mine.cuda(self.device_index)
