@@ -375,3 +375,89 @@ def test_lattice_replicas_are_independent_streams():
         np.testing.assert_array_equal(got, ora.ising2d_sweep(s0, True, table, 9, 11, 0, replica=rep))
         outs.append(got)
     assert (outs[0] != outs[1]).mean() > 0.2 and (outs[1] != outs[2]).mean() > 0.2
+
+
+# ------------------------------------------------------------------ no stale device copies
+def test_in_place_edit_of_one_off_diagonal_entry_of_a_2048_J_is_seen():
+    """The reference reads ``coupling`` afresh at every site (gibbs.py:97).  Edit ONE unsampled off-diagonal entry of a
+    2048 x 2048 J in place between two gibbs_sweep calls (same array object, same address, and a second, sum-preserving
+    edit): the second call must run on the edited matrix, i.e. equal the oracle run on it."""
+    from tsu.gibbs import GibbsConfig, GibbsSampler
+    n = 2048
+    rng = np.random.default_rng(5)
+    J = rng.normal(size=(n, n)) / np.sqrt(n)
+    J = (J + J.T) / 2
+    st = rng.integers(0, 2, size=n)
+    s = GibbsSampler(GibbsConfig(temperature=1.0), seed=77)
+    out1 = s.gibbs_sweep(st, J, None, n_sweeps=1)
+    want1 = ora.dense_sweep_philox(st.astype(np.int8), J, None, 1.0, 1, 77, sweep0=0)
+    np.testing.assert_array_equal(out1, want1)
+    # a strong coupling between two sites no strided probe of round 1 looked at; sum-preserving pair of edits
+    J[5, 1001] += 40.0
+    J[7, 1003] -= 40.0
+    out2 = s.gibbs_sweep(st, J, None, n_sweeps=1)
+    want2 = ora.dense_sweep_philox(st.astype(np.int8), J, None, 1.0, 1, 77, sweep0=1)
+    np.testing.assert_array_equal(out2, want2)
+    stale = ora.dense_sweep_philox(st.astype(np.int8), J - 0, None, 1.0, 1, 77, sweep0=1)
+    np.testing.assert_array_equal(stale, want2)   # (same matrix: sanity of the oracle call)
+    # bind() is the explicit opt-out: the caller promises not to edit; the device copy is then reused without a look
+    s2 = GibbsSampler(GibbsConfig(temperature=1.0), seed=77).bind(J, None)
+    a = s2.gibbs_sweep(st, J, None, n_sweeps=1)
+    np.testing.assert_array_equal(a, ora.dense_sweep_philox(st.astype(np.int8), J, None, 1.0, 1, 77, sweep0=0))
+    s2.unbind()
+    J[5, 1001] -= 40.0
+    b = s2.gibbs_sweep(st, J, None, n_sweeps=1)
+    np.testing.assert_array_equal(b, ora.dense_sweep_philox(st.astype(np.int8), J, None, 1.0, 1, 77, sweep0=1))
+
+
+def test_ising_model_sample_sees_set_coupling_between_calls():
+    """IsingModel.sample passes a fresh ``4 * J`` temporary each call (its address is recycled): content decides."""
+    from tsu.models.ising import IsingConfig, IsingModel
+    m = IsingModel(6, config=IsingConfig(temperature=0.3, n_burnin=50, n_sweeps=2), bias_mode="physical")
+    for i in range(5):
+        m.set_coupling(i, i + 1, 2.0)
+    np.random.seed(3)
+    s = m.sample(200)
+    assert np.mean(s[:, 0] * s[:, 1]) > 0.9
+    m.set_coupling(0, 1, -2.0)           # same J array, edited in place by the reference's own setter
+    s = m.sample(200)
+    assert np.mean(s[:, 0] * s[:, 1]) < -0.9
+
+
+def test_ising_grid_J_edited_in_place_leaves_the_lattice_kernel():
+    from tsu.models.ising import IsingConfig, IsingGrid
+    g = IsingGrid((4, 4), J=1.0, config=IsingConfig(temperature=0.4, n_burnin=80, n_sweeps=2), periodic=True, bias_mode="physical")
+    np.random.seed(4)
+    s = g.sample(300)
+    assert g._lattice_ok()
+    assert np.mean(s[:, 0] * s[:, 1]) > 0.8
+    J = g.J                               # dense view handed out ...
+    assert g._lattice_ok()                # ... and untouched: still the lattice kernel
+    J[0, 1] = J[1, 0] = -6.0              # ... edited in place, as the reference allows
+    s = g.sample(300)
+    assert not g._lattice_ok()
+    assert np.mean(s[:, 0] * s[:, 1]) < -0.8
+
+
+def test_two_contexts_in_one_process():
+    """Per-device kernel attributes / occupancy live in the context: a second context (on a second GPU when there is
+    one, else a second context on the same GPU) runs the 160 KB-LDS kernels from a clean state, and an entry point runs
+    on its context's device whatever the caller's current device is."""
+    import torch
+    from tsu import _hip
+    n_dev = torch.cuda.device_count()
+    dev2 = 1 if n_dev > 1 else 0
+    table = ora.ising2d_thresholds(1.0, 0.0, 2.269185, 0)
+    ctxs = [_hip.Context(0), _hip.Context(dev2)]
+    if n_dev > 1:
+        torch.cuda.set_device(0)          # the caller's current device is NOT the second context's
+    for ctx in ctxs:
+        lat = _hip.Lattice(256, 1024, True, ctx=ctx)
+        lat.randomize(11)
+        lat.set_thresholds(table)
+        lat.sweep(24, 11, 0)              # > 8 sweeps: the tile-resident kernel (LDS attribute + occupancy query)
+        want = ora.ising2d_sweep(ora.ising2d_randomize(256, 1024, 11), True, table, 24, 11, 0)
+        np.testing.assert_array_equal(lat.get_spins(), want)
+        lat.close()
+    if n_dev > 1:
+        assert torch.cuda.current_device() == 0

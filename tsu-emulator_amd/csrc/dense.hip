@@ -357,13 +357,11 @@ static hipError_t k2w_launch(const tsu_dense* d, int m, hipStream_t stream, cons
     static const k2w_run_fn table[2][K2W_MAX_SLOTS] = {
         {(k2w_run_fn)k2_small<float, 1>, (k2w_run_fn)k2_small<float, 2>, (k2w_run_fn)k2_small<float, 3>},
         {(k2w_run_fn)k2_small<double, 1>, (k2w_run_fn)k2_small<double, 2>, nullptr}};
-    static bool attr[2][K2W_MAX_SLOTS] = {};
     const int ti = d->dtype == TSU_DTYPE_F64 ? 1 : 0;
     const k2w_run_fn fn = table[ti][m - 1];
-    if (!attr[ti][m - 1]) {
-        hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    {
+        hipError_t e = tsu_func_allow_lds(d->ctx, (const void*)fn, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr[ti][m - 1] = true;
     }
     hipLaunchKernelGGL(fn, dim3(1), dim3(64), k2w_lds_bytes(d, m), stream, (const void*)d->J, (const double*)d->bias, d->state, uniforms, samples,
                        d->n, T, temps, n_burnin, n_sweeps, n_samples, sweep0, tag, k0, k1);
@@ -375,13 +373,11 @@ static hipError_t k2w_launch_replicas(const tsu_dense* d, int m, hipStream_t str
     static const k2w_rep_fn table[2][K2W_MAX_SLOTS] = {
         {(k2w_rep_fn)k2_small_replicas<float, 1>, (k2w_rep_fn)k2_small_replicas<float, 2>, (k2w_rep_fn)k2_small_replicas<float, 3>},
         {(k2w_rep_fn)k2_small_replicas<double, 1>, (k2w_rep_fn)k2_small_replicas<double, 2>, nullptr}};
-    static bool attr[2][K2W_MAX_SLOTS] = {};
     const int ti = d->dtype == TSU_DTYPE_F64 ? 1 : 0;
     const k2w_rep_fn fn = table[ti][m - 1];
-    if (!attr[ti][m - 1]) {
-        hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    {
+        hipError_t e = tsu_func_allow_lds(d->ctx, (const void*)fn, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr[ti][m - 1] = true;
     }
     hipLaunchKernelGGL(fn, dim3((unsigned)n_replicas), dim3(64), k2w_lds_bytes(d, m), stream, (const void*)d->J, (const double*)d->bias, states,
                        uniforms, reps, d->n, n_sweeps);
@@ -785,6 +781,7 @@ static int dense_sweep_impl(tsu_dense* d, double T, int n_sweeps, bool have_orde
 extern "C" {
 
 int tsu_dense_create(tsu_ctx* ctx, int n, const void* J_host, int dtype, const double* bias_host, tsu_dense** out) {
+    TSU_ENTER(ctx);
     if (!ctx || !out) return TSU_E_INVALID;
     *out = nullptr;
     TSU_REQUIRE(ctx, n >= 1 && J_host, "Coupling matrix must be square");
@@ -851,6 +848,7 @@ int tsu_dense_create(tsu_ctx* ctx, int n, const void* J_host, int dtype, const d
 }
 
 int tsu_dense_destroy(tsu_dense* d) {
+    TSU_ENTER(d ? d->ctx : nullptr);
     if (!d) return TSU_OK;
     (void)hipStreamSynchronize(d->ctx->stream);
     if (d->JT && d->JT != d->J) (void)hipFree(d->JT);
@@ -882,6 +880,7 @@ int tsu_dense_destroy(tsu_dense* d) {
 }
 
 int tsu_dense_set_state(tsu_dense* d, const int8_t* bits_host) {
+    TSU_ENTER(d ? d->ctx : nullptr);
     if (!d) return TSU_E_INVALID;
     TSU_REQUIRE(d->ctx, bits_host != nullptr, "dense_set_state: NULL");
     for (int i = 0; i < d->n; ++i) TSU_REQUIRE(d->ctx, bits_host[i] == 0 || bits_host[i] == 1, "dense_set_state: state must be 0/1");
@@ -891,6 +890,7 @@ int tsu_dense_set_state(tsu_dense* d, const int8_t* bits_host) {
 }
 
 int tsu_dense_get_state(tsu_dense* d, int8_t* bits_host) {
+    TSU_ENTER(d ? d->ctx : nullptr);
     if (!d) return TSU_E_INVALID;
     TSU_REQUIRE(d->ctx, bits_host != nullptr, "dense_get_state: NULL");
     TSU_HIP_TRY(d->ctx, hipMemcpyAsync(bits_host, d->state, (size_t)d->n, hipMemcpyDeviceToHost, d->ctx->stream));
@@ -900,6 +900,7 @@ int tsu_dense_get_state(tsu_dense* d, int8_t* bits_host) {
 
 int tsu_dense_sweep(tsu_dense* d, double T, int n_sweeps, const int64_t* order, uint64_t seed, uint32_t sweep0,
                     uint32_t replica, const double* replay_uniforms) {
+    TSU_ENTER(d ? d->ctx : nullptr);
     if (!d) return TSU_E_INVALID;
     tsu_ctx* ctx = d->ctx;
     TSU_REQUIRE(ctx, T > 0.0, "Temperature must be positive");
@@ -1079,12 +1080,14 @@ static int dense_run(tsu_dense* d, double T, const double* temps, int n_burnin, 
 
 int tsu_dense_sample(tsu_dense* d, double T, int n_burnin, int n_sweeps, int n_samples, const int64_t* order, uint64_t seed,
                      uint32_t sweep0, uint32_t replica, const double* replay_uniforms, int8_t* samples_host) {
+    TSU_ENTER(d ? d->ctx : nullptr);
     if (!d) return TSU_E_INVALID;
     return dense_run(d, T, nullptr, n_burnin, n_sweeps, n_samples, order, seed, sweep0, replica, replay_uniforms, samples_host);
 }
 
 int tsu_dense_anneal(tsu_dense* d, const double* temperatures, int n_steps, const int64_t* order, uint64_t seed, uint32_t sweep0,
                      uint32_t replica, const double* replay_uniforms, int8_t* states_host) {
+    TSU_ENTER(d ? d->ctx : nullptr);
     if (!d) return TSU_E_INVALID;
     TSU_REQUIRE(d->ctx, n_steps >= 0 && (n_steps == 0 || temperatures), "dense_anneal: need n_steps >= 0 and a temperature per step");
     for (int s = 0; s < n_steps; ++s) TSU_REQUIRE(d->ctx, temperatures[s] > 0.0, "Temperature must be positive");
@@ -1093,6 +1096,7 @@ int tsu_dense_anneal(tsu_dense* d, const double* temperatures, int n_steps, cons
 
 int tsu_dense_sweep_replicas(tsu_dense* d, int n_replicas, const double* temperatures, int n_sweeps, int8_t* states_host,
                              const uint64_t* seeds, const uint32_t* sweep0s, const uint32_t* replicas, const double* replay_uniforms) {
+    TSU_ENTER(d ? d->ctx : nullptr);
     if (!d) return TSU_E_INVALID;
     tsu_ctx* ctx = d->ctx;
     TSU_REQUIRE(ctx, n_replicas >= 1 && temperatures && states_host && seeds && sweep0s && replicas,
@@ -1152,6 +1156,7 @@ int tsu_dense_sweep_replicas(tsu_dense* d, int n_replicas, const double* tempera
 }
 
 int tsu_dense_energy(tsu_dense* d, double* energy) {
+    TSU_ENTER(d ? d->ctx : nullptr);
     if (!d) return TSU_E_INVALID;
     tsu_ctx* ctx = d->ctx;
     TSU_REQUIRE(ctx, energy != nullptr, "dense_energy: NULL");

@@ -396,13 +396,12 @@ static int coop_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint3
     const bool vec = (n % JVec<TJ>::W) == 0;
     void (*kern)(CoopParams) = vec ? k2_coop<TJ, true> : k2_coop<TJ, false>;
     const size_t lds_bytes = (size_t)((n > SB_SIZE ? n : SB_SIZE) + 15) / 16 * 16;
-    if (lds_bytes > 48 * 1024 &&
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
+    if (lds_bytes > 48 * 1024 && tsu_func_allow_lds(ctx, (const void*)kern, (int)lds_bytes) != hipSuccess) {
         (void)hipGetLastError();
         return TSU_OK;
     }
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, CO_THREADS, lds_bytes) != hipSuccess || per_cu < 1) {
+    if (tsu_func_blocks_per_cu(ctx, (const void*)kern, CO_THREADS, lds_bytes, &per_cu) != hipSuccess || per_cu < 1) {
         (void)hipGetLastError();
         d->co_disabled = 1;
         return TSU_OK;

@@ -409,6 +409,7 @@ int tsu_ising2d_thresholds(double J, double h, double T, int mode, uint64_t tabl
 
 int tsu_ising2d_create_slab(tsu_ctx* ctx, int64_t total_rows, int cols, int periodic, int64_t row0, int rows, int ghost,
                             tsu_ising2d** out) {
+    TSU_ENTER(ctx);
     if (!ctx || !out) return TSU_E_INVALID;
     *out = nullptr;
     TSU_REQUIRE(ctx, total_rows >= 1 && cols >= 1 && rows >= 1, "ising2d: rows/cols must be positive");
@@ -473,10 +474,12 @@ int tsu_ising2d_create_slab(tsu_ctx* ctx, int64_t total_rows, int cols, int peri
 }
 
 int tsu_ising2d_create(tsu_ctx* ctx, int rows, int cols, int periodic, tsu_ising2d** out) {
+    TSU_ENTER(ctx);
     return tsu_ising2d_create_slab(ctx, rows, cols, periodic, 0, rows, 0, out);
 }
 
 int tsu_ising2d_destroy(tsu_ising2d* L) {
+    TSU_ENTER(L ? L->ctx : nullptr);
     if (!L) return TSU_OK;
     (void)hipStreamSynchronize(L->ctx->stream);
     for (int i = 0; i < 2; ++i)
@@ -494,6 +497,7 @@ int tsu_ising2d_destroy(tsu_ising2d* L) {
 }
 
 int tsu_ising2d_set_spins(tsu_ising2d* L, const int8_t* host, int row_first, int n_rows) {
+    TSU_ENTER(L ? L->ctx : nullptr);
     if (!L) return TSU_E_INVALID;
     tsu_ctx* ctx = L->ctx;
     TSU_REQUIRE(ctx, host && n_rows >= 0 && row_first >= -L->ghost && row_first + n_rows <= L->rows + L->ghost,
@@ -516,6 +520,7 @@ static int check_persist_error(tsu_ising2d* L) {
 }
 
 int tsu_ising2d_get_spins(tsu_ising2d* L, int8_t* host, int row_first, int n_rows) {
+    TSU_ENTER(L ? L->ctx : nullptr);
     if (!L) return TSU_E_INVALID;
     tsu_ctx* ctx = L->ctx;
     TSU_REQUIRE(ctx, host && n_rows >= 0 && row_first >= -L->ghost && row_first + n_rows <= L->rows + L->ghost,
@@ -530,6 +535,7 @@ int tsu_ising2d_get_spins(tsu_ising2d* L, int8_t* host, int row_first, int n_row
 }
 
 int tsu_ising2d_randomize(tsu_ising2d* L, uint64_t seed, uint32_t replica) {
+    TSU_ENTER(L ? L->ctx : nullptr);
     if (!L) return TSU_E_INVALID;
     tsu_ctx* ctx = L->ctx;
     K1Params p = make_params(L, L->alloc[L->cur]);
@@ -543,6 +549,7 @@ int tsu_ising2d_randomize(tsu_ising2d* L, uint64_t seed, uint32_t replica) {
 }
 
 int tsu_ising2d_fill(tsu_ising2d* L, int8_t value) {
+    TSU_ENTER(L ? L->ctx : nullptr);
     if (!L) return TSU_E_INVALID;
     tsu_ctx* ctx = L->ctx;
     TSU_REQUIRE(ctx, value == 1 || value == -1, "ising2d_fill: value must be +1 or -1");
@@ -555,6 +562,7 @@ int tsu_ising2d_fill(tsu_ising2d* L, int8_t value) {
 }
 
 int tsu_ising2d_set_thresholds(tsu_ising2d* L, const uint64_t table[25]) {
+    TSU_ENTER(L ? L->ctx : nullptr);
     if (!L) return TSU_E_INVALID;
     TSU_REQUIRE(L->ctx, table != nullptr, "ising2d_set_thresholds: table is NULL");
     for (int i = 0; i < 25; ++i) {
@@ -566,6 +574,7 @@ int tsu_ising2d_set_thresholds(tsu_ising2d* L, const uint64_t table[25]) {
 }
 
 int tsu_ising2d_set_model(tsu_ising2d* L, double J, double h, double T, int mode) {
+    TSU_ENTER(L ? L->ctx : nullptr);
     if (!L) return TSU_E_INVALID;
     TSU_REQUIRE(L->ctx, T > 0.0, "Temperature must be positive");
     TSU_REQUIRE(L->ctx, mode == TSU_MODE_PHYSICAL || mode == TSU_MODE_COMPAT, "ising2d_set_model: bad mode %d", mode);
@@ -575,6 +584,7 @@ int tsu_ising2d_set_model(tsu_ising2d* L, double J, double h, double T, int mode
 }
 
 int tsu_ising2d_set_kernel(tsu_ising2d* L, int kernel, int sweeps_per_launch) {
+    TSU_ENTER(L ? L->ctx : nullptr);
     if (!L) return TSU_E_INVALID;
     TSU_REQUIRE(L->ctx, kernel >= TSU_KERNEL_AUTO && kernel <= TSU_KERNEL_SMALL, "ising2d_set_kernel: bad kernel %d", kernel);
     TSU_REQUIRE(L->ctx, sweeps_per_launch >= 0 && sweeps_per_launch <= 16, "ising2d_set_kernel: sweeps_per_launch in [0,16]");
@@ -588,10 +598,12 @@ int tsu_ising2d_set_kernel(tsu_ising2d* L, int kernel, int sweeps_per_launch) {
 }
 
 int tsu_ising2d_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_t sweep0, uint32_t replica) {
+    TSU_ENTER(L ? L->ctx : nullptr);
     return tsu_ising2d_sweep_part(L, n_sweeps, seed, sweep0, replica, TSU_PART_ALL);
 }
 
 int tsu_ising2d_sweep_part(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_t sweep0, uint32_t replica, int part) {
+    TSU_ENTER(L ? L->ctx : nullptr);
     if (!L) return TSU_E_INVALID;
     tsu_ctx* ctx = L->ctx;
     TSU_REQUIRE(ctx, part >= TSU_PART_ALL && part <= TSU_PART_BOUNDARY, "ising2d_sweep_part: bad part %d", part);
@@ -623,11 +635,7 @@ int tsu_ising2d_sweep_part(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_t
         const int nchunks = (L->cols + 15) >> 4, tasks = L->rows * nchunks;
         const unsigned threads = tasks >= 1024 ? 1024u : (unsigned)((tasks + 63) / 64 * 64);
         const size_t lds_bytes = (size_t)tasks * 16;
-        static bool attr_set = false;
-        if (!attr_set) {
-            TSU_HIP_TRY(ctx, hipFuncSetAttribute((const void*)k1_small, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-            attr_set = true;
-        }
+        TSU_HIP_TRY(ctx, tsu_func_allow_lds(ctx, (const void*)k1_small, 128 * 1024));
         k1_small<<<1, threads, lds_bytes, ctx->stream>>>(p, tbl, sweep0, n_sweeps);
         L->launches += 1;
         TSU_HIP_TRY(ctx, hipGetLastError());
@@ -667,6 +675,7 @@ int tsu_ising2d_sweep_part(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_t
 }
 
 int tsu_ising2d_set_timing(tsu_ising2d* L, int enable) {
+    TSU_ENTER(L ? L->ctx : nullptr);
     if (!L) return TSU_E_INVALID;
     L->timing = enable != 0;
     L->timed = 0;
@@ -674,12 +683,14 @@ int tsu_ising2d_set_timing(tsu_ising2d* L, int enable) {
 }
 
 int tsu_ising2d_launch_count(tsu_ising2d* L, uint64_t* n) {
+    TSU_ENTER(L ? L->ctx : nullptr);
     if (!L || !n) return TSU_E_INVALID;
     *n = L->launches;
     return TSU_OK;
 }
 
 int tsu_ising2d_last_sweep_ms(tsu_ising2d* L, float* ms) {
+    TSU_ENTER(L ? L->ctx : nullptr);
     if (!L || !ms) return TSU_E_INVALID;
     TSU_REQUIRE(L->ctx, L->timed, "ising2d_last_sweep_ms: no sweep has been timed (tsu_ising2d_set_timing(lat, 1), then sweep)");
     TSU_HIP_TRY(L->ctx, hipEventSynchronize(L->ev1));
@@ -688,6 +699,7 @@ int tsu_ising2d_last_sweep_ms(tsu_ising2d* L, float* ms) {
 }
 
 int tsu_ising2d_observables(tsu_ising2d* L, int64_t* sum_s, int64_t* sum_bonds) {
+    TSU_ENTER(L ? L->ctx : nullptr);
     if (!L) return TSU_E_INVALID;
     tsu_ctx* ctx = L->ctx;
     TSU_REQUIRE(ctx, sum_s && sum_bonds, "ising2d_observables: NULL output");
@@ -707,6 +719,7 @@ int tsu_ising2d_observables(tsu_ising2d* L, int64_t* sum_s, int64_t* sum_bonds) 
 
 int tsu_ising2d_sample(tsu_ising2d* L, int n_burnin, int n_sweeps, int n_samples, uint64_t seed, uint32_t sweep0, uint32_t replica,
                        int8_t* samples_host) {
+    TSU_ENTER(L ? L->ctx : nullptr);
     if (!L) return TSU_E_INVALID;
     tsu_ctx* ctx = L->ctx;
     TSU_REQUIRE(ctx, n_burnin >= 0 && n_sweeps > 0 && n_samples >= 0, "ising2d_sample: need n_burnin >= 0, n_sweeps > 0, n_samples >= 0");
@@ -735,6 +748,7 @@ int tsu_ising2d_sample(tsu_ising2d* L, int n_burnin, int n_sweeps, int n_samples
 
 int tsu_ising2d_sweep_batch(tsu_ising2d* const* lats, int n_lats, int n_sweeps, const uint64_t* seeds, const uint32_t* sweep0s,
                             const uint32_t* replicas) {
+    TSU_ENTER((lats && n_lats > 0 && lats[0]) ? lats[0]->ctx : nullptr);
     if (!lats || n_lats < 1 || !lats[0]) return TSU_E_INVALID;
     tsu_ctx* ctx = lats[0]->ctx;
     TSU_REQUIRE(ctx, seeds && sweep0s && replicas, "ising2d_sweep_batch: seeds, sweep0s and replicas are per-lattice arrays");
@@ -828,6 +842,7 @@ int tsu_ising2d_sweep_batch(tsu_ising2d* const* lats, int n_lats, int n_sweeps, 
 }
 
 int tsu_ising2d_observables_batch(tsu_ising2d* const* lats, int n_lats, int64_t* sum_s, int64_t* sum_bonds) {
+    TSU_ENTER((lats && n_lats > 0 && lats[0]) ? lats[0]->ctx : nullptr);
     if (!lats || n_lats < 1 || !lats[0]) return TSU_E_INVALID;
     tsu_ctx* ctx = lats[0]->ctx;
     TSU_REQUIRE(ctx, sum_s && sum_bonds, "ising2d_observables: NULL output");
@@ -862,6 +877,7 @@ int tsu_ising2d_observables_batch(tsu_ising2d* const* lats, int n_lats, int64_t*
 }
 
 int tsu_ising2d_row_ptr(tsu_ising2d* L, int local_row, void** device_ptr, size_t* pitch_bytes) {
+    TSU_ENTER(L ? L->ctx : nullptr);
     if (!L) return TSU_E_INVALID;
     TSU_REQUIRE(L->ctx, device_ptr && local_row >= -L->ghost && local_row < L->rows + L->ghost,
                 "ising2d_row_ptr: row %d outside [%d, %d)", local_row, -L->ghost, L->rows + L->ghost);

@@ -36,7 +36,6 @@ struct TiledParams {
     int k;                       // sweeps in this launch
     int tiles_x;
     int ty_first, ty_stride;     // tile row of block b: ty_first + (b / tiles_x) * ty_stride
-    int debug;                   // development timing aid (TSU_K1_DEBUG): 1 = skip HBM loads, 2 = skip loads and stores
     uint32_t k0, k1, sweep0, tag_hi, tag_lo;
     uint32_t tblH0, tblH1, tblL0, tblL1;  // (min(thr >> 16, 65535) ^ 0x8000) for up = 0..4, split into byte tables
     uint32_t t3H0, t3H1, t3L0, t3L1;      // open lattices: the same for degree 3 (entries 0..3) and degree 2 (entries 4..6)
@@ -344,7 +343,7 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
     auto first_sites = [](int n) { return n >= 8 ? 0x0101010101010101ull : (((1ull << (8 * n)) - 1) & 0x0101010101010101ull); };
     const uint64_t vm_e = first_sites((nv + 1) >> 1), vm_o = first_sites(nv >> 1);
 
-    if (!p.debug && al < RLMAX) {
+    if (al < RLMAX) {
         const int8_t* col = src + 16 * (long long)(OPEN ? (cqi < 0 ? 0 : (cqi >= p.nchunks ? p.nchunks - 1 : cqi)) : cqi);
         // four rows per step, all four 16-byte loads in flight before the first is converted: the stage is one
         // HBM latency per step, so fewer, wider steps
@@ -596,7 +595,7 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
         for (int q = 0; q < 4; ++q) R->dbg[q] = tl[q];
 #undef RES_MARK
     // interior octets are tile columns 1 .. NO-2: the same thread -> column mapping, halo columns idle
-    if (p.debug < 2 && al < RLMAX && oct >= 1 && oct <= WO && q0 + oct - 1 < p.nchunks + p.q_shift) {
+    if (al < RLMAX && oct >= 1 && oct <= WO && q0 + oct - 1 < p.nchunks + p.q_shift) {
         int8_t* col = dst + 16 * (long long)cqi;  // (= q0 + oct - 1, wrapped when the tiling starts at octet q_shift)
         int gpar = (int)((p.row0 + r0 + al) & 1);
 #pragma unroll 2
@@ -657,40 +656,19 @@ struct TileVariant {
     void (*open)(TiledParams);       // open-boundary form (nullptr: not built for this shape)
     void (*resident_open)(ResidentLaunch);
 };
-// tile shapes compiled in; TSU_TILE_VARIANT (env, development aid) or tsu_ising2d_set_kernel picks one
+// the tile shapes the chooser (pick_variant) can reach.  Round 1's table had 32 entries, 24 of them reachable only through
+// the TSU_TILE_VARIANT development switch; numbers quoted in profiles/r01_* map as 6 -> 0, 8 -> 1, 9 -> 2, 22 -> 3, 23 -> 4,
+// 25 -> 5, 26 -> 6, 27 -> 7
+enum { V_64x512_T512 = 0, V_128x512_T512, V_128x512_T1024, V_256x512_T1024, V_128x256_T1024, V_64x512_T1024, V_64x256_T1024, V_32x256_T1024 };
 const TileVariant kVariants[] = {
-    {64, 32, 256, k1_tiled2<64, 32, 256>},     // 0..5: shapes of the first-generation kernel (removed), kept so that
-    {64, 32, 512, k1_tiled2<64, 32, 512>},     //       the variant numbers quoted in profiles/ stay valid
-    {128, 32, 512, k1_tiled2<128, 32, 512>},
-    {64, 64, 512, k1_tiled2<64, 64, 512>},
-    {32, 32, 256, k1_tiled2<32, 32, 256>},
-    {128, 32, 1024, k1_tiled2<128, 32, 1024>},
-    {64, 32, 512, k1_tiled2<64, 32, 512>, k1_resident<64, 32, 512>, k1_tiled2<64, 32, 512, 1, true>},    // 6
-    {64, 32, 256, k1_tiled2<64, 32, 256>},    // 7
-    {128, 32, 512, k1_tiled2<128, 32, 512>, k1_resident<128, 32, 512>, k1_tiled2<128, 32, 512, 1, true>},  // 8
-    {128, 32, 1024, k1_tiled2<128, 32, 1024>, k1_resident<128, 32, 1024>, k1_tiled2<128, 32, 1024, 1, true>, k1_resident<128, 32, 1024, 1, true>},// 9
-    {64, 32, 1024, k1_tiled2<64, 32, 1024>},  // 10
-    {64, 32, 576, k1_tiled2<64, 32, 576>},    // 11
-    {128, 32, 640, k1_tiled2<128, 32, 640>},  // 12
-    {128, 32, 832, k1_tiled2<128, 32, 832>},  // 13
-    {96, 32, 512, k1_tiled2<96, 32, 512>},    // 14
-    {96, 32, 768, k1_tiled2<96, 32, 768>},    // 15
-    {64, 32, 512, k1_tiled2<64, 32, 512, 6>, nullptr},   // 16: <= 80 VGPRs -> 3 workgroups per CU
-    {64, 32, 512, k1_tiled2<64, 32, 512, 8>},   // 17: <= 64 VGPRs -> 4 workgroups per CU (LDS permitting)
-    {64, 32, 256, k1_tiled2<64, 32, 256, 8>},   // 18
-    {128, 32, 512, k1_tiled2<128, 32, 512, 6>, nullptr}, // 19
-    {128, 32, 768, k1_tiled2<128, 32, 768, 6>}, // 20: 12 waves per workgroup, 2 workgroups per CU = 6 waves/SIMD
-    {128, 32, 640, k1_tiled2<128, 32, 640, 5>}, // 21
-    {256, 32, 1024, k1_tiled2<256, 32, 1024, 4>, k1_resident<256, 32, 1024, 4>, k1_tiled2<256, 32, 1024, 4, true>, k1_resident<256, 32, 1024, 4, true>}, // 22: one 148 KB workgroup per CU
-    {128, 16, 1024, k1_tiled2<128, 16, 1024>, k1_resident<128, 16, 1024>, k1_tiled2<128, 16, 1024, 1, true>, k1_resident<128, 16, 1024, 1, true>},  // 23: narrower tiles for mid-size lattices
-    {64, 16, 512, k1_tiled2<64, 16, 512>, k1_resident<64, 16, 512>},        // 24
-    {64, 32, 1024, k1_tiled2<64, 32, 1024>, k1_resident<64, 32, 1024>, k1_tiled2<64, 32, 1024, 1, true>, k1_resident<64, 32, 1024, 1, true>},     // 25
-    {64, 16, 1024, k1_tiled2<64, 16, 1024>, k1_resident<64, 16, 1024>, k1_tiled2<64, 16, 1024, 1, true>, k1_resident<64, 16, 1024, 1, true>},  // 26
-    {32, 16, 1024, k1_tiled2<32, 16, 1024>, k1_resident<32, 16, 1024>, k1_tiled2<32, 16, 1024, 1, true>, k1_resident<32, 16, 1024, 1, true>},     // 27
-    {112, 32, 512, k1_tiled2<112, 32, 512>},      // 23
-    {96, 32, 512, k1_tiled2<96, 32, 512, 6>},     // 24
-    {160, 32, 512, k1_tiled2<160, 32, 512>},      // 25
-    {192, 32, 1024, k1_tiled2<192, 32, 1024>},    // 26
+    {64, 32, 512, k1_tiled2<64, 32, 512>, k1_resident<64, 32, 512>, k1_tiled2<64, 32, 512, 1, true>},
+    {128, 32, 512, k1_tiled2<128, 32, 512>, k1_resident<128, 32, 512>, k1_tiled2<128, 32, 512, 1, true>},
+    {128, 32, 1024, k1_tiled2<128, 32, 1024>, k1_resident<128, 32, 1024>, k1_tiled2<128, 32, 1024, 1, true>, k1_resident<128, 32, 1024, 1, true>},
+    {256, 32, 1024, k1_tiled2<256, 32, 1024, 4>, k1_resident<256, 32, 1024, 4>, k1_tiled2<256, 32, 1024, 4, true>, k1_resident<256, 32, 1024, 4, true>},  // one 148 KB workgroup per CU
+    {128, 16, 1024, k1_tiled2<128, 16, 1024>, k1_resident<128, 16, 1024>, k1_tiled2<128, 16, 1024, 1, true>, k1_resident<128, 16, 1024, 1, true>},  // narrower tiles for mid-size lattices
+    {64, 32, 1024, k1_tiled2<64, 32, 1024>, k1_resident<64, 32, 1024>, k1_tiled2<64, 32, 1024, 1, true>, k1_resident<64, 32, 1024, 1, true>},
+    {64, 16, 1024, k1_tiled2<64, 16, 1024>, k1_resident<64, 16, 1024>, k1_tiled2<64, 16, 1024, 1, true>, k1_resident<64, 16, 1024, 1, true>},
+    {32, 16, 1024, k1_tiled2<32, 16, 1024>, k1_resident<32, 16, 1024>, k1_tiled2<32, 16, 1024, 1, true>, k1_resident<32, 16, 1024, 1, true>},
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -730,16 +708,16 @@ int pick_variant(const tsu_ising2d* L) {
         const int cus = L->ctx->cus > 0 ? L->ctx->cus : 256;
         const long long tx = (((L->cols + 15) / 16) + 31) / 32;
         const long long n128 = ((L->rows + 127) / 128) * tx, n256 = ((L->rows + 255) / 256) * tx;
-        if (n128 <= cus) v = 9;
-        else if (n128 <= 2 * cus && n256 <= cus && 10 * n256 >= 7 * cus) v = 22;
-        else v = 8;
-        if (L->rows < 256) v = 6;
+        if (n128 <= cus) v = V_128x512_T1024;
+        else if (n128 <= 2 * cus && n256 <= cus && 10 * n256 >= 7 * cus) v = V_256x512_T1024;
+        else v = V_128x512_T512;
+        if (L->rows < 256) v = V_64x512_T512;
         // Lattices that give every CU at most one tile: the tile shape that finishes a generation of 8 sweeps soonest.
         // Model fitted to measurements (4096^2, 2048^2, 1024^2, 4096 x 8192, open 1000^2; profiles/r01_k1_experiments.txt):
         // a half-sweep costs 0.25 us + 0.225 us per wave-iteration of the busiest SIMD; between generations the strip
         // exchange costs 4.3 us when the tiles stay resident in LDS (the lattice divides into whole tiles), the tile
         // store + launch gap + stage about 12 us when they do not.
-        static const int cand[] = {22, 9, 23, 25, 26, 27};
+        static const int cand[] = {V_256x512_T1024, V_128x512_T1024, V_128x256_T1024, V_64x512_T1024, V_64x256_T1024, V_32x256_T1024};
         double best = 1e30;
         const bool whole = L->ghost == 0 && L->total_rows == L->rows;
         const int nch = (L->cols + 15) / 16;
@@ -765,7 +743,7 @@ int pick_variant(const tsu_ising2d* L) {
                ragged_shift(L, kVariants[vv].WO) >= 0;
     };
     if (!fits(v)) {
-        static const int fallback[] = {6, 26, 27};
+        static const int fallback[] = {V_64x512_T512, V_64x256_T1024, V_32x256_T1024};
         v = -1;
         for (int f : fallback)
             if (fits(f)) {
@@ -832,14 +810,6 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
     p.ghost = L->ghost;
     p.tiles_x = (p.nchunks + TILE_WO - 1) / TILE_WO;
     p.q_shift = ragged_shift(L, TILE_WO);
-    {
-        static int dbg = -1;
-        if (dbg < 0) {
-            const char* e = getenv("TSU_K1_DEBUG");
-            dbg = e ? atoi(e) : 0;
-        }
-        p.debug = dbg;
-    }
     p.r_begin = 0;
     p.r_end = L->rows;
     p.tile_h = TILE_H;
@@ -868,11 +838,7 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
     p.tblH0 = (t16[0] >> 8) | ((t16[1] >> 8) << 8) | ((t16[2] >> 8) << 16) | ((t16[3] >> 8) << 24);
     p.tblH1 = (t16[4] >> 8);
     void (*const kern)(TiledParams) = L->periodic ? tv.kernel : tv.open;
-    static bool attr_set[kNumVariants][2] = {};
-    if (!attr_set[&tv - kVariants][p.open]) {
-        TSU_HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set[&tv - kVariants][p.open] = true;
-    }
+    TSU_HIP_TRY(ctx, tsu_func_allow_lds(ctx, (const void*)kern, 160 * 1024));
     static int use_resident = -1;
     if (use_resident < 0) {
         const char* e = getenv("TSU_K1_RESIDENT");
@@ -883,7 +849,7 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
     // later generations need (uniform even height th, th * tiles_y = rows + 2 ext, 2 (n_sweeps - k) <= ext <= ghost)
     int res_th = TILE_H, res_ext = 0;
     void (*const res_kern)(ResidentLaunch) = L->periodic ? tv.resident : tv.resident_open;
-    bool res_ok = use_resident && res_kern && part == TSU_PART_ALL && n_sweeps > kmax && !p.debug && p.nchunks % TILE_WO == 0;
+    bool res_ok = use_resident && res_kern && part == TSU_PART_ALL && n_sweeps > kmax && p.nchunks % TILE_WO == 0;
     if (res_ok && (L->wrap_rows || open_whole)) res_ok = L->rows % TILE_H == 0;
     else if (res_ok) {
         const int need = L->rows + 4 * (n_sweeps - kmax);
@@ -900,20 +866,11 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
         // ---- tile-resident generations: every tile has its own workgroup on the chip for the whole call
         const int vi = (int)(&tv - kVariants);
         const size_t lds_bytes = ((size_t)2 * (res_th + 4 * kmax) * TILE_NO + TILE_NO + 2 + 25) * sizeof(uint64_t);
-        static bool rattr_[kNumVariants][2] = {};
-        static int per_cu_[kNumVariants][2] = {};
-        bool& rattr_vi = rattr_[vi][p.open];
-        if (!rattr_vi) {
-            TSU_HIP_TRY(ctx, hipFuncSetAttribute((const void*)res_kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            int per_cu = 0;
-            // (occupancy for the standard tile height; a stretched slab tile was checked against the variant's LDS share)
-            TSU_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                                 &per_cu, (const void*)res_kern, tv.threads,
-                                 ((size_t)2 * (TILE_H + 4 * KMAX) * TILE_NO + TILE_NO + 2 + 25) * sizeof(uint64_t)));
-            per_cu_[vi][p.open] = per_cu;
-            rattr_vi = true;
-        }
-        const int fit_per_cu = per_cu_[vi][p.open];
+        TSU_HIP_TRY(ctx, tsu_func_allow_lds(ctx, (const void*)res_kern, 160 * 1024));
+        int fit_per_cu = 0;
+        // (occupancy for the standard tile height; a stretched slab tile was checked against the variant's LDS share)
+        TSU_HIP_TRY(ctx, tsu_func_blocks_per_cu(ctx, (const void*)res_kern, tv.threads,
+                                                ((size_t)2 * (TILE_H + 4 * KMAX) * TILE_NO + TILE_NO + 2 + 25) * sizeof(uint64_t), &fit_per_cu));
         if ((long long)ntiles <= (long long)fit_per_cu * ctx->cus) {
             const size_t xstride = (size_t)4 * (2 * kmax * TILE_WO) + (size_t)4 * res_th;
             const size_t xneed = (size_t)2 * ntiles * xstride;

@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void k3_restart(float* __restrict__ x, const f
 extern "C" {
 
 int tsu_langevin_create(tsu_ctx* ctx, int n_chains, int dim, tsu_langevin** out) {
+    TSU_ENTER(ctx);
     if (!ctx || !out) return TSU_E_INVALID;
     *out = nullptr;
     TSU_REQUIRE(ctx, n_chains >= 1 && dim >= 1, "langevin_create: n_chains and dim must be positive");
@@ -117,6 +118,7 @@ int tsu_langevin_create(tsu_ctx* ctx, int n_chains, int dim, tsu_langevin** out)
 }
 
 int tsu_langevin_destroy(tsu_langevin* l) {
+    TSU_ENTER(l ? l->ctx : nullptr);
     if (!l) return TSU_OK;
     (void)hipStreamSynchronize(l->ctx->stream);
     for (float* p : {l->x, l->k, l->mu, l->xinit})
@@ -126,6 +128,7 @@ int tsu_langevin_destroy(tsu_langevin* l) {
 }
 
 int tsu_langevin_set_state(tsu_langevin* l, const float* x_host) {
+    TSU_ENTER(l ? l->ctx : nullptr);
     if (!l) return TSU_E_INVALID;
     TSU_REQUIRE(l->ctx, x_host != nullptr, "langevin_set_state: NULL");
     size_t w = (size_t)l->dim * sizeof(float);
@@ -136,6 +139,7 @@ int tsu_langevin_set_state(tsu_langevin* l, const float* x_host) {
 }
 
 int tsu_langevin_get_state(tsu_langevin* l, float* x_host) {
+    TSU_ENTER(l ? l->ctx : nullptr);
     if (!l) return TSU_E_INVALID;
     TSU_REQUIRE(l->ctx, x_host != nullptr, "langevin_get_state: NULL");
     size_t w = (size_t)l->dim * sizeof(float);
@@ -146,6 +150,7 @@ int tsu_langevin_get_state(tsu_langevin* l, float* x_host) {
 }
 
 int tsu_langevin_set_energy(tsu_langevin* l, const float* k_host, const float* mu_host) {
+    TSU_ENTER(l ? l->ctx : nullptr);
     if (!l) return TSU_E_INVALID;
     TSU_REQUIRE(l->ctx, k_host && mu_host, "langevin_set_energy: NULL");
     size_t w = (size_t)l->dim * sizeof(float);
@@ -157,6 +162,7 @@ int tsu_langevin_set_energy(tsu_langevin* l, const float* k_host, const float* m
 }
 
 int tsu_langevin_set_kernel(tsu_langevin* l, int steps_per_launch) {
+    TSU_ENTER(l ? l->ctx : nullptr);
     if (!l) return TSU_E_INVALID;
     TSU_REQUIRE(l->ctx, steps_per_launch >= 0, "langevin_set_kernel: steps_per_launch must be >= 0");
     l->steps_per_launch = steps_per_launch;
@@ -164,6 +170,7 @@ int tsu_langevin_set_kernel(tsu_langevin* l, int steps_per_launch) {
 }
 
 int tsu_langevin_restart(tsu_langevin* l, const float* x_init_host, float amp, uint64_t seed, uint32_t chain0) {
+    TSU_ENTER(l ? l->ctx : nullptr);
     if (!l) return TSU_E_INVALID;
     tsu_ctx* ctx = l->ctx;
     TSU_REQUIRE(ctx, x_init_host != nullptr, "langevin_restart: NULL");
@@ -179,6 +186,7 @@ int tsu_langevin_restart(tsu_langevin* l, const float* x_init_host, float amp, u
 
 int tsu_langevin_step(tsu_langevin* l, int n_steps, float dt, float gamma, float T, uint64_t seed, uint32_t step0,
                       uint32_t chain0, float* traj_host) {
+    TSU_ENTER(l ? l->ctx : nullptr);
     if (!l) return TSU_E_INVALID;
     tsu_ctx* ctx = l->ctx;
     TSU_REQUIRE(ctx, n_steps >= 0, "langevin_step: n_steps must be >= 0");

@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <unordered_map>
+
 #include "../../include/tsu_hip.h"
 
 struct tsu_ctx {
@@ -19,7 +21,32 @@ struct tsu_ctx {
     hipEvent_t fork_ev;
     int pool_n;
     int in_batch;  // inside tsu_ising2d_sweep_batch: the batch itself bounds how many co-resident grids are in flight
+    // per-DEVICE facts about kernels (a function attribute and an occupancy figure belong to the device they were set /
+    // asked on): kept in the context, never in process-wide statics -- a second context on another GPU sets its own
+    std::unordered_map<const void*, int> lds_attr;    // kernel -> MaxDynamicSharedMemorySize already granted
+    std::unordered_map<uint64_t, int> blocks_per_cu;  // hash(kernel, threads, lds) -> occupancy answer
 };
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (context, kernel); cached occupancy query
+hipError_t tsu_func_allow_lds(tsu_ctx* ctx, const void* fn, int bytes);
+hipError_t tsu_func_blocks_per_cu(tsu_ctx* ctx, const void* fn, int threads, size_t lds_bytes, int* per_cu);
+
+// Every extern "C" entry point runs on its context's device whatever the caller's current device is (torch.cuda.set_device,
+// a second context, ...), and leaves the caller's current device as it found it.
+struct tsu_device_guard {
+    int prev = -1;
+    bool switched = false;
+    explicit tsu_device_guard(const tsu_ctx* ctx) {
+        if (!ctx) return;
+        if (hipGetDevice(&prev) == hipSuccess && prev != ctx->device) switched = hipSetDevice(ctx->device) == hipSuccess;
+    }
+    ~tsu_device_guard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    tsu_device_guard(const tsu_device_guard&) = delete;
+    tsu_device_guard& operator=(const tsu_device_guard&) = delete;
+};
+#define TSU_ENTER(ctx_expr) tsu_device_guard tsu_guard__(ctx_expr)
 
 // Kernels that synchronise inside the grid (k1_resident, k2_coop) need all their workgroups on the chip at once.  Two
 // of them launched on different streams of this process could each get part of the chip and wait for the rest, so

@@ -37,6 +37,26 @@ int tsu_grid_exclusive_end(tsu_ctx* ctx) {
     return TSU_OK;
 }
 
+hipError_t tsu_func_allow_lds(tsu_ctx* ctx, const void* fn, int bytes) {
+    auto it = ctx->lds_attr.find(fn);
+    if (it != ctx->lds_attr.end() && it->second >= bytes) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) ctx->lds_attr[fn] = bytes;
+    return e;
+}
+
+hipError_t tsu_func_blocks_per_cu(tsu_ctx* ctx, const void* fn, int threads, size_t lds_bytes, int* per_cu) {
+    const uint64_t key = (uint64_t)(uintptr_t)fn * 0x9E3779B97F4A7C15ull ^ ((uint64_t)threads << 40) ^ (uint64_t)lds_bytes;
+    auto it = ctx->blocks_per_cu.find(key);
+    if (it != ctx->blocks_per_cu.end()) {
+        *per_cu = it->second;
+        return hipSuccess;
+    }
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, fn, threads, lds_bytes);
+    if (e == hipSuccess) ctx->blocks_per_cu[key] = *per_cu;
+    return e;
+}
+
 extern "C" {
 
 int tsu_version(void) { return 100; }
@@ -79,6 +99,7 @@ int tsu_init(int device, tsu_ctx** out) {
 }
 
 int tsu_shutdown(tsu_ctx* ctx) {
+    TSU_ENTER(ctx);
     if (!ctx) return TSU_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
@@ -103,12 +124,14 @@ int tsu_set_stream(tsu_ctx* ctx, void* hip_stream) {
 }
 
 int tsu_synchronize(tsu_ctx* ctx) {
+    TSU_ENTER(ctx);
     if (!ctx) return TSU_E_INVALID;
     TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TSU_OK;
 }
 
 int tsu_device_info(tsu_ctx* ctx, char* name, int name_len, int* compute_units, uint64_t* hbm_bytes) {
+    TSU_ENTER(ctx);
     if (!ctx) return TSU_E_INVALID;
     hipDeviceProp_t prop;
     TSU_HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
@@ -119,12 +142,14 @@ int tsu_device_info(tsu_ctx* ctx, char* name, int name_len, int* compute_units, 
 }
 
 int tsu_timer_begin(tsu_ctx* ctx) {
+    TSU_ENTER(ctx);
     if (!ctx) return TSU_E_INVALID;
     TSU_HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     return TSU_OK;
 }
 
 int tsu_timer_end(tsu_ctx* ctx, float* elapsed_ms) {
+    TSU_ENTER(ctx);
     if (!ctx || !elapsed_ms) return TSU_E_INVALID;
     TSU_HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     TSU_HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
@@ -146,6 +171,7 @@ __global__ void philox_kat_kernel(int n, const uint32_t* __restrict__ ctrs, uint
 }
 
 extern "C" int tsu_philox4x32_10(tsu_ctx* ctx, int n, const uint32_t* ctrs, const uint32_t* key, uint32_t* out) {
+    TSU_ENTER(ctx);
     if (!ctx) return TSU_E_INVALID;
     TSU_REQUIRE(ctx, n > 0 && ctrs && key && out, "tsu_philox4x32_10: bad arguments");
     uint32_t *d_in = nullptr, *d_out = nullptr;

@@ -23,7 +23,7 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 from .. import _hip
-from ..gibbs import GibbsConfig, GibbsSampler
+from ..gibbs import GibbsConfig, GibbsSampler, _content_key
 
 
 @dataclass
@@ -207,7 +207,8 @@ class IsingGrid(IsingModel):
         self.periodic = periodic
         self.coupling = float(J)
         self._J = None          # built on first access
-        self._custom = False    # set_coupling() was called: no longer a uniform lattice
+        self._custom = False    # set_coupling() was called / J was edited: no longer a uniform lattice
+        self._J_key = None
         self.h = np.ones(self.n_spins) * self.config.external_field
         gibbs_config = GibbsConfig(temperature=self.config.temperature, n_burnin=self.config.n_burnin,
                                    n_sweeps=self.config.n_sweeps)
@@ -224,6 +225,7 @@ class IsingGrid(IsingModel):
                 raise MemoryError(f"dense J for {self.n_spins} spins would need {8 * self.n_spins ** 2 / 2 ** 30:.0f} GiB; "
                                   "the lattice kernel does not need it")
             self._J = _grid_coupling(self.rows, self.cols, self.coupling, self.periodic)
+            self._J_key = _content_key(self._J)
         return self._J
 
     @J.setter
@@ -231,13 +233,24 @@ class IsingGrid(IsingModel):
         self._J = np.asarray(value, dtype=float)
         self._custom = True
 
+    def _J_edited_in_place(self) -> bool:
+        """The reference lets callers write into ``grid.J`` and samples from whatever it holds (ising.py:150-181 reads
+        ``self.J`` at call time).  Once the dense matrix has been handed out, every sampling call therefore checks
+        (full content hash) that it still is the uniform lattice before taking the lattice kernel."""
+        if self._J is None or self._custom:
+            return False
+        if _content_key(self._J) != self._J_key:
+            self._custom = True
+            return True
+        return False
+
     def set_coupling(self, i: int, j: int, strength: float):
         super().set_coupling(i, j, strength)
         self._custom = True
 
     # ------------------------------------------------------------------ lattice kernel plumbing
     def _lattice_ok(self) -> bool:
-        if self._custom or np.any(self.h != self.h[0]):
+        if self._custom or self._J_edited_in_place() or np.any(self.h != self.h[0]):
             return False
         if self.periodic and (self.rows % 2 or self.cols % 2 or self.rows < 4 or self.cols < 4):
             return False  # no 2-colouring (and the reference's size-1/2 wrap bonds are special): dense path
