@@ -7,6 +7,8 @@ reference's own random stream can be replayed (rng="numpy")."""
 import numpy as np
 import pytest
 
+from oracle import oracle as ora
+
 pytestmark = pytest.mark.gpu
 
 
@@ -398,8 +400,11 @@ def test_in_place_edit_of_one_off_diagonal_entry_of_a_2048_J_is_seen():
     out2 = s.gibbs_sweep(st, J, None, n_sweeps=1)
     want2 = ora.dense_sweep_philox(st.astype(np.int8), J, None, 1.0, 1, 77, sweep0=1)
     np.testing.assert_array_equal(out2, want2)
-    stale = ora.dense_sweep_philox(st.astype(np.int8), J - 0, None, 1.0, 1, 77, sweep0=1)
-    np.testing.assert_array_equal(stale, want2)   # (same matrix: sanity of the oracle call)
+    J0 = J.copy()
+    J0[5, 1001] -= 40.0
+    J0[7, 1003] += 40.0
+    stale = ora.dense_sweep_philox(st.astype(np.int8), J0, None, 1.0, 1, 77, sweep0=1)
+    assert (stale != want2).any()                 # the edit matters: a stale device copy would give another state
     # bind() is the explicit opt-out: the caller promises not to edit; the device copy is then reused without a look
     s2 = GibbsSampler(GibbsConfig(temperature=1.0), seed=77).bind(J, None)
     a = s2.gibbs_sweep(st, J, None, n_sweeps=1)

@@ -455,27 +455,14 @@ static int coop_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint3
     int grid = ctx->cus;
     const int useful = (n + CO_THREADS / 64 - 1) / (CO_THREADS / 64);
     if (grid > useful) grid = useful;
-    // The grid is one workgroup per CU at most and fits the device (occupancy query above), so an ordinary launch makes
-    // all workgroups resident unless another process holds CUs for good; the bounded wait in the barrier turns that
-    // case into the fallback below instead of a hang.  TSU_K2_COOP_LAUNCH=1 asks the runtime for a cooperative launch
-    // instead (same kernel; rocprofv3 crashes at process exit after profiling one, hence not the default).
-    static int coop_api = -1;
-    if (coop_api < 0) {
-        const char* ev = getenv("TSU_K2_COOP_LAUNCH");
-        coop_api = ev ? atoi(ev) : 0;
-    }
+    // The grid is one workgroup per CU at most and fits the device (occupancy query above); the launch goes through
+    // tsu_launch_grid_sync (cooperative API by default).  The bounded wait in the barrier stays: it turns a GPU shared
+    // with another process's long kernel into the fallback below instead of a hang.
     {
         const int rcx = tsu_grid_exclusive_begin(ctx);
         if (rcx != TSU_OK) return rcx;
     }
-    hipError_t e;
-    if (coop_api) {
-        void* args[] = {&P};
-        e = hipLaunchCooperativeKernel((const void*)kern, dim3((unsigned)grid), dim3(CO_THREADS), args, (unsigned)lds_bytes, ctx->stream);
-    } else {
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(CO_THREADS), lds_bytes, ctx->stream, P);
-        e = hipGetLastError();
-    }
+    hipError_t e = tsu_launch_grid_sync(ctx, (const void*)kern, dim3((unsigned)grid), dim3(CO_THREADS), &P, lds_bytes, ctx->stream);
     if (e != hipSuccess) {  // launch not possible in this configuration: not an error, use the other path
         (void)hipGetLastError();
         d->co_disabled = 1;

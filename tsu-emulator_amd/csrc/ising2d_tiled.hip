@@ -937,10 +937,9 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
                 // the numbering restarts (or another strip layout starts): no element may look like one of the new run
                 // (after the chaining above: an earlier launch of this lattice on another stream has finished with the buffer)
                 if (renumber) TSU_HIP_TRY(ctx, hipMemsetAsync(L->d_xbuf, 0, L->xbuf_cap * sizeof(uint64_t), ctx->stream));
-                hipLaunchKernelGGL(res_kern, dim3((unsigned)ntiles), dim3((unsigned)tv.threads), lds_bytes, ctx->stream, P);
+                TSU_HIP_TRY(ctx, tsu_launch_grid_sync(ctx, (const void*)res_kern, dim3((unsigned)ntiles), dim3((unsigned)tv.threads), &P, lds_bytes, ctx->stream));
                 L->launches += 1;
                 L->cur ^= 1;
-                TSU_HIP_TRY(ctx, hipGetLastError());
                 {
                     const int rcx = tsu_grid_exclusive_end(ctx);
                     if (rcx != TSU_OK) return rcx;

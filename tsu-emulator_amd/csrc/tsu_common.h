@@ -55,6 +55,18 @@ struct tsu_device_guard {
 int tsu_grid_exclusive_begin(tsu_ctx* ctx);
 int tsu_grid_exclusive_end(tsu_ctx* ctx);
 
+// Launch of a kernel that synchronises inside its grid.  Default: hipLaunchCooperativeKernel, so that co-residency of the
+// whole grid is the runtime's promise (it refuses a grid that cannot be resident) instead of this library's arithmetic.
+// TSU_COOP_LAUNCH=0 selects an ordinary launch of the same grid (same residency in practice: the grid was sized from the
+// occupancy query); that is also what is used while the rocprofiler-sdk tool library is loaded in the process, because on
+// ROCm 7.2 hsa_shut_down() crashes at process exit after a cooperative launch under rocprofv3 (DESIGN.md section 8,
+// profiles/r02_exit_crash_symbolised.txt) -- TSU_COOP_LAUNCH=1 forces the cooperative API even then.  Inside a batch of
+// lattices (tsu_ising2d_sweep_batch: several small grids share the chip on side streams, their number bounded by the batch
+// itself) the launches are ordinary: the runtime serialises cooperative launches on one queue (measured: 32 lattices of
+// 512 x 512, 2500 sweeps: 248 ms against 87 ms; profiles/r02_coop_launch_cost.txt).
+bool tsu_use_coop_launch();
+hipError_t tsu_launch_grid_sync(tsu_ctx* ctx, const void* kernel, dim3 grid, dim3 block, void* param_struct, size_t lds_bytes, hipStream_t stream);
+
 extern thread_local char g_tsu_init_err[512];
 
 int tsu_fail(tsu_ctx* ctx, int code, const char* fmt, ...);

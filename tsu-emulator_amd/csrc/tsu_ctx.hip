@@ -1,5 +1,6 @@
 // tsu_ctx.hip -- context, stream, timers, error text, device-side Philox known-answer entry point.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "tsu_common.h"
 
@@ -35,6 +36,34 @@ int tsu_grid_exclusive_end(tsu_ctx* ctx) {
     if (ctx->in_batch || ctx->device < 0 || ctx->device >= kMaxDevices || !g_grid_ev_made[ctx->device]) return TSU_OK;
     TSU_HIP_TRY(ctx, hipEventRecord(g_grid_ev[ctx->device], ctx->stream));
     return TSU_OK;
+}
+
+bool tsu_use_coop_launch() {
+    static int mode = -1;  // process-wide by nature: an environment switch and "is a profiler attached to this process"
+    if (mode < 0) {
+        const char* e = getenv("TSU_COOP_LAUNCH");
+        if (e && *e) {
+            mode = atoi(e) ? 1 : 0;
+        } else {
+            mode = 1;
+            if (FILE* f = fopen("/proc/self/maps", "r")) {
+                char line[1024];
+                while (fgets(line, sizeof line, f))
+                    if (strstr(line, "librocprofiler-sdk-tool")) {
+                        mode = 0;
+                        break;
+                    }
+                fclose(f);
+            }
+        }
+    }
+    return mode == 1;
+}
+
+hipError_t tsu_launch_grid_sync(tsu_ctx* ctx, const void* kernel, dim3 grid, dim3 block, void* param_struct, size_t lds_bytes, hipStream_t stream) {
+    void* args[] = {param_struct};
+    if (tsu_use_coop_launch() && !ctx->in_batch) return hipLaunchCooperativeKernel(kernel, grid, block, args, (unsigned)lds_bytes, stream);
+    return hipLaunchKernel(kernel, grid, block, args, lds_bytes, stream);
 }
 
 hipError_t tsu_func_allow_lds(tsu_ctx* ctx, const void* fn, int bytes) {

@@ -3,9 +3,11 @@
 There is deliberately no CPU fallback in this package: if the HIP library is missing or no GPU is
 present, every operation that needs it raises :class:`HipUnavailableError`.
 """
+import atexit
 import ctypes as C
 import os
 import sys
+import weakref
 
 import numpy as np
 
@@ -120,6 +122,22 @@ def _ptr(a, t):
     return a.ctypes.data_as(t)
 
 
+_live_contexts = weakref.WeakSet()
+
+
+@atexit.register
+def _shutdown_contexts():
+    """Deterministic teardown at interpreter exit (before the HIP runtime's own exit handlers): every context still
+    alive is synchronised and its streams / events are destroyed (``__del__`` is not reliable at finalisation)."""
+    for ctx in list(_live_contexts):
+        try:
+            if getattr(ctx, "h", None):
+                ctx.lib.tsu_shutdown(ctx.h)
+                ctx.h = None
+        except Exception:
+            pass
+
+
 class Context:
     """One tsu_ctx (one GPU).  ``Context.default()`` is the per-process singleton used by the API layer."""
 
@@ -133,6 +151,7 @@ class Context:
             msg = self.lib.tsu_last_error(None).decode()
             raise HipUnavailableError(f"tsu_init failed ({rc}): {msg}")
         self.h = h
+        _live_contexts.add(self)
 
     @classmethod
     def default(cls):
