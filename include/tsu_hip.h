@@ -51,6 +51,7 @@ typedef struct tsu_ctx tsu_ctx;
 typedef struct tsu_ising2d tsu_ising2d;
 typedef struct tsu_dense tsu_dense;
 typedef struct tsu_langevin tsu_langevin;
+typedef struct tsu_sparse tsu_sparse;
 
 /* ------------------------------------------------------------------ context */
 int tsu_version(void);
@@ -188,6 +189,30 @@ int tsu_dense_sweep_replicas(tsu_dense* d, int n_replicas, const double* tempera
                              const uint64_t* seeds, const uint32_t* sweep0s, const uint32_t* replicas,
                              const double* replay_uniforms);
 int tsu_dense_energy(tsu_dense* d, double* energy); /* -1/2 s^T J s - b^T s of the resident state */
+
+/* ------------------------------------------------------------------ sparse coupling graph, colour-parallel (K5)
+ * Replaces GibbsSampler.gibbs_sweep / sample_boltzmann / compute_energy (tsu/gibbs.py:79-236) for models whose
+ * coupling matrix is sparse -- IsingChain (tsu/models/ising.py:265-304) and IsingModel on an arbitrary graph
+ * (:39-97) at sizes where the dense N x N matrix of the reference cannot exist (a 10^6-site chain would be 8 TB).
+ * The graph comes as CSR (row i: columns col_idx[row_ptr[i] .. row_ptr[i+1]) ascending, bit couplings `values`, the
+ * diagonal entry J_ii allowed: gibbs.py:97 includes it in the local field) plus a proper colouring: `order` lists the
+ * sites colour by colour, color_offsets[c] .. color_offsets[c+1] delimit colour c in it, and no two sites of one colour
+ * are coupled.  A sweep visits the colours in order and updates all sites of a colour at once -- the same outcome as
+ * the reference's sequential loop run in the visiting order `order` (sites of one colour do not read each other).
+ * Decision rule, field (float64) and the Philox uniform keyed by (site, sweep) are those of the dense path (K2).
+ */
+int tsu_sparse_create(tsu_ctx* ctx, int n, const int64_t* row_ptr /*n+1*/, const int32_t* col_idx, const double* values,
+                      const double* bias_host /*nullable, n*/, int n_colors, const int32_t* color_offsets /*n_colors+1*/,
+                      const int32_t* order /*n*/, tsu_sparse** out);
+int tsu_sparse_destroy(tsu_sparse* g);
+int tsu_sparse_set_state(tsu_sparse* g, const int8_t* bits_host); /* n bits {0,1}, site order */
+int tsu_sparse_get_state(tsu_sparse* g, int8_t* bits_host);
+int tsu_sparse_sweep(tsu_sparse* g, double T, int n_sweeps, uint64_t seed, uint32_t sweep0, uint32_t replica);
+/* n_burnin sweeps, then n_samples x (n_sweeps sweeps, record): samples_host receives n_samples*n bits (site order) */
+int tsu_sparse_sample(tsu_sparse* g, double T, int n_burnin, int n_sweeps, int n_samples, uint64_t seed, uint32_t sweep0,
+                      uint32_t replica, int8_t* samples_host);
+/* -1/2 s^T J s - b^T s of the resident state, and sum_i (2 s_i - 1) (the magnetisation numerator in spin language) */
+int tsu_sparse_energy(tsu_sparse* g, double* energy, int64_t* sum_spins);
 
 /* ------------------------------------------------------------------ Langevin (K3)
  * Replaces ThermalSamplingUnit._langevin_step (tsu/core.py:64-80) fused with the analytic gradient of a

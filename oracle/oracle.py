@@ -51,6 +51,7 @@ def lib():
         _lib.ora_sigmoid.argtypes = [C.c_double]
         _lib.ora_dense_energy.restype = C.c_double
         _lib.ora_dense_uniform.restype = C.c_double
+        _lib.ora_sparse_energy.restype = C.c_double
         _lib.ora_dense_uniform.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32]
     return _lib
 
@@ -300,6 +301,32 @@ def dense_sweep_philox(state, J, bias, T, n_sweeps, seed, sweep0=0, replica=0, o
                                  None if o is None else _p(o, C.c_int64), C.c_uint64(seed), C.c_uint32(sweep0),
                                  C.c_uint32(replica))
     return st
+
+
+def sparse_sweep_philox(state, row_ptr, col, val, bias, T, n_sweeps, seed, sweep0=0, replica=0, order=None):
+    """K5 twin: sequential heat-bath sweeps on a CSR graph in the visiting order ``order`` (n sites, the same every sweep).
+    Reference loop: tsu/gibbs.py:128-162; field incl. the diagonal entry: gibbs.py:97."""
+    st = np.ascontiguousarray(state, dtype=np.int8).copy()
+    n = st.size
+    rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
+    ci = np.ascontiguousarray(col, dtype=np.int32)
+    va = np.ascontiguousarray(val, dtype=np.float64)
+    b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float64)
+    o = None if order is None else np.ascontiguousarray(order, dtype=np.int32)
+    lib().ora_sparse_sweep_philox(_p(st, C.c_int8), _p(rp, C.c_int64), _p(ci, C.c_int32), _p(va, C.c_double),
+                                  None if b is None else _p(b, C.c_double), C.c_int(n), C.c_double(T), C.c_int(n_sweeps),
+                                  None if o is None else _p(o, C.c_int32), C.c_uint64(seed), C.c_uint32(sweep0), C.c_uint32(replica))
+    return st
+
+
+def sparse_energy(state, row_ptr, col, val, bias):
+    st = np.ascontiguousarray(state, dtype=np.int8)
+    rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
+    ci = np.ascontiguousarray(col, dtype=np.int32)
+    va = np.ascontiguousarray(val, dtype=np.float64)
+    b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float64)
+    return float(lib().ora_sparse_energy(_p(st, C.c_int8), _p(rp, C.c_int64), _p(ci, C.c_int32), _p(va, C.c_double),
+                                         None if b is None else _p(b, C.c_double), C.c_int(st.size)))
 
 
 TAG_LANGEVIN = 3

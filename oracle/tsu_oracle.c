@@ -23,7 +23,7 @@
  *        - ora_philox4x32_10        (Salmon et al. SC'11; KATs in tests)
  *        - ora_ising2d_thresholds   <- tsu/models/ising.py:138,148 + tsu/gibbs.py:61-77,125
  *        - ora_ising2d_randomize / ora_ising2d_sweep / ora_ising2d_observables
- *        - ora_dense_sweep_philox
+ *        - ora_dense_sweep_philox, ora_sparse_sweep_philox (the same loop on a CSR graph, coloured visiting order)
  *        - ora_langevin_quadratic_f32
  */
 #include <math.h>
@@ -286,6 +286,38 @@ void ora_dense_sweep_philox(int8_t *state, const double *J, const double *bias, 
             state[i] = (ora_dense_uniform((uint32_t)i, sweep0 + (uint32_t)s, seed, replica) < p) ? 1 : 0;
         }
     }
+}
+
+/*
+ * Sparse twin of ora_dense_sweep_philox (K5): the same sequential heat-bath loop (gibbs.py:128-162) with the local field
+ * summed over the CSR row of the site (columns ascending, diagonal entry included when present: gibbs.py:97) instead of
+ * the dense row.  order: n site indices visited each sweep (the colour-major order of a proper colouring: sites of one
+ * colour do not read each other, so this sequential loop equals the device's colour-parallel update).
+ */
+void ora_sparse_sweep_philox(int8_t *state, const int64_t *row_ptr, const int32_t *col, const double *val, const double *bias,
+                             int n, double T, int n_sweeps, const int32_t *order, uint64_t seed, uint32_t sweep0,
+                             uint32_t replica) {
+    for (int s = 0; s < n_sweeps; ++s) {
+        for (int k = 0; k < n; ++k) {
+            int i = order ? order[k] : k;
+            double h = 0.0;
+            for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) h += val[e] * (double)state[col[e]];
+            if (bias) h += bias[i];
+            double p = ora_sigmoid(h / T);
+            state[i] = (ora_dense_uniform((uint32_t)i, sweep0 + (uint32_t)s, seed, replica) < p) ? 1 : 0;
+        }
+    }
+}
+
+/* -1/2 s^T J s - b^T s on the CSR graph (gibbs.py:215-236) */
+double ora_sparse_energy(const int8_t *state, const int64_t *row_ptr, const int32_t *col, const double *val, const double *bias, int n) {
+    double e = 0.0;
+    for (int i = 0; i < n; ++i) {
+        double h = 0.0;
+        for (int64_t q = row_ptr[i]; q < row_ptr[i + 1]; ++q) h += val[q] * (double)state[col[q]];
+        e += -0.5 * (double)state[i] * h - (bias ? bias[i] : 0.0) * (double)state[i];
+    }
+    return e;
 }
 
 /* ================================================================== (B) device order: Langevin */

@@ -1,0 +1,152 @@
+"""K5 parity (-m gpu): the colour-parallel sparse kernel through the C ABI against the oracle's sparse twin (bit-exact),
+the drop-in surface on sparse models, and exact 1-D results at a size the reference's dense matrix cannot reach."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import oracle as ora
+from test_sparse_cpu import colors_of, random_graph  # noqa: F401  (tests/ is on sys.path: rootdir conftest, prepend import mode)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    from tsu import _hip
+    _hip.Context.default()
+
+
+def _chain(n, J=1.0):
+    from tsu.graph import canonical_csr
+    return canonical_csr(sp.diags([np.full(n - 1, J), np.full(n - 1, J)], [1, -1]))
+
+
+@pytest.mark.parametrize("name,n", [("chain", 1), ("chain", 2), ("chain", 7), ("chain", 4097), ("chain", 32768), ("chain", 32769),
+                                    ("chain", 300001), ("graph", 5000), ("graph", 60000), ("empty", 1000)])
+def test_sparse_sweep_matches_oracle(name, n):
+    from tsu import _hip
+    from tsu.graph import canonical_csr, color_graph
+    rng = np.random.default_rng(n)
+    if name == "chain":
+        A = _chain(n, 0.8) if n > 1 else canonical_csr(sp.csr_matrix((1, 1)))
+    elif name == "graph":
+        A = random_graph(n, 3.0 / n, n)            # mean degree ~6 incl. symmetrisation, self-loops on 20 % of the sites
+    else:
+        A = canonical_csr(sp.csr_matrix((n, n)))
+    bias = rng.normal(size=n)
+    st = rng.integers(0, 2, size=n).astype(np.int8)
+    offsets, order = color_graph(A)
+    g = _hip.SparseSystem(A.indptr, A.indices, A.data, bias, offsets, order)
+    g.set_state(st)
+    np.testing.assert_array_equal(g.get_state(), st)
+    g.sweep(0.9, 3, seed=99, sweep0=5)
+    want = ora.sparse_sweep_philox(st, A.indptr, A.indices, A.data, bias, 0.9, 3, 99, sweep0=5, order=order)
+    got = g.get_state()
+    np.testing.assert_array_equal(got, want)
+    e, m = g.energy()
+    assert e == pytest.approx(ora.sparse_energy(want, A.indptr, A.indices, A.data, bias), rel=1e-12, abs=1e-9 * n)
+    assert m == int((2 * want.astype(int) - 1).sum())
+    # sampling run: burn-in 2, 3 samples 2 sweeps apart, counters continue
+    smp = g.sample(0.9, 2, 2, 3, seed=99, sweep0=8)
+    cur = want
+    cur = ora.sparse_sweep_philox(cur, A.indptr, A.indices, A.data, bias, 0.9, 2, 99, sweep0=8, order=order)
+    for k in range(3):
+        cur = ora.sparse_sweep_philox(cur, A.indptr, A.indices, A.data, bias, 0.9, 2, 99, sweep0=10 + 2 * k, order=order)
+        np.testing.assert_array_equal(smp[k], cur)
+    np.testing.assert_array_equal(g.get_state(), cur)
+    g.close()
+
+
+def test_sparse_create_rejects_bad_input():
+    from tsu import _hip
+    A = _chain(6)
+    off, order = np.array([0, 3, 6], np.int32), np.array([0, 2, 4, 1, 3, 5], np.int32)
+    _hip.SparseSystem(A.indptr, A.indices, A.data, None, off, order).close()
+    with pytest.raises(ValueError, match="same colour"):
+        _hip.SparseSystem(A.indptr, A.indices, A.data, None, off, np.array([0, 1, 2, 3, 4, 5], np.int32))
+    with pytest.raises(ValueError, match="permutation"):
+        _hip.SparseSystem(A.indptr, A.indices, A.data, None, off, np.array([0, 2, 4, 1, 3, 3], np.int32))
+    with pytest.raises(ValueError, match="offsets"):
+        _hip.SparseSystem(A.indptr, A.indices, A.data, None, np.array([0, 3, 5], np.int32), order)
+    g = _hip.SparseSystem(A.indptr, A.indices, A.data, None, off, order)
+    with pytest.raises(ValueError, match="Temperature must be positive"):
+        g.sweep(0.0, 1)
+    g.close()
+
+
+def test_gibbs_sampler_accepts_scipy_sparse_couplings():
+    """gibbs_sweep / sample_boltzmann / compute_energy with a scipy.sparse J == the reference loop (dense oracle) run in
+    the colour-major visiting order, with the Philox uniforms of (site, sweep)."""
+    from tsu.gibbs import GibbsConfig, GibbsSampler
+    from tsu.graph import color_graph
+    n = 300
+    A = random_graph(n, 0.02, 11)
+    rng = np.random.default_rng(11)
+    bias = rng.normal(size=n)
+    st = rng.integers(0, 2, size=n)
+    _, order = color_graph(A)
+    s = GibbsSampler(GibbsConfig(temperature=0.7, n_burnin=3, n_sweeps=2), seed=4242)
+    out = s.gibbs_sweep(st, A, bias, n_sweeps=4)
+    want = ora.dense_sweep_philox(st.astype(np.int8), A.toarray(), bias, 0.7, 4, 4242, sweep0=0, order=np.tile(order, (4, 1)))
+    np.testing.assert_array_equal(out, want)
+    assert out.dtype == st.dtype and s._sweep_counter == 4
+    smp = s.sample_boltzmann(A, bias, n_samples=5, initial_state=out)
+    assert smp.shape == (5, n) and smp.dtype == np.zeros(1, dtype=int).dtype and s.sample_count == 5
+    cur = ora.dense_sweep_philox(want, A.toarray(), bias, 0.7, 3, 4242, sweep0=4, order=np.tile(order, (3, 1)))
+    for k in range(5):
+        cur = ora.dense_sweep_philox(cur, A.toarray(), bias, 0.7, 2, 4242, sweep0=7 + 2 * k, order=np.tile(order, (2, 1)))
+        np.testing.assert_array_equal(smp[k], cur)
+    b = cur.astype(float)
+    assert s.compute_energy(cur, A, bias) == pytest.approx(-0.5 * b @ A.toarray() @ b - bias @ b, abs=1e-9)
+    with pytest.raises(ValueError):
+        GibbsSampler(rng="numpy").gibbs_sweep(st, A, bias)
+    with pytest.raises(ValueError, match="square"):
+        s.sample_boltzmann(sp.csr_matrix((3, 4)))
+
+
+def test_sparse_three_spin_model_samples_the_exact_boltzmann_distribution(golden):
+    """The reference's own 3-spin fixture (g9: chain + a frustrating bond, field 0.2, T = 1.5): histogram of 40 000 samples
+    of the sparse path against exact enumeration (both bias modes; compat = the reference's shipped sign)."""
+    from tsu.models.ising import IsingConfig, IsingModel
+    g9 = golden("g9_distribution")
+    J, h, T = g9["n3_J"], g9["n3_h"], float(g9["n3_T"])
+    for mode in ("physical", "compat"):
+        m = IsingModel(3, config=IsingConfig(temperature=T, external_field=0.2, n_burnin=50, n_sweeps=3), bias_mode=mode, graph="sparse")
+        m.set_coupling(0, 1, 1.0)
+        m.set_coupling(1, 2, 1.0)
+        m.set_coupling(0, 2, -0.5)
+        np.testing.assert_array_equal(m.J, J)
+        np.random.seed(5)
+        s = m.sample(40000)
+        code = ((s + 1) // 2).dot(1 << np.arange(3))
+        hist = np.bincount(code, minlength=8) / 40000.0
+        # exact distribution of what the sampler is fed: bits with couplings 4J and the mode's bias
+        Jb, hb = 4 * J, m._get_bit_bias()
+        states = np.array([[(c >> k) & 1 for k in range(3)] for c in range(8)], dtype=float)
+        E = np.array([-0.5 * b @ Jb @ b - hb @ b for b in states])
+        p = np.exp(-E / T)
+        p /= p.sum()
+        assert np.abs(hist - p).max() < 0.01, (mode, hist, p)
+        ref = g9[f"n3_hist_{mode}"] / 4000.0        # the reference's own 4000-sample histogram
+        assert np.abs(hist - ref).max() < 0.04, (mode, hist, ref)
+
+
+def test_million_site_chain_nearest_neighbour_correlation():
+    """IsingChain with 10^6 sites (the reference's dense J would need 8 TB): open chain, h = 0, physical bias:
+    <s_i s_{i+1}> = tanh(J/T) exactly, <s_i s_{i+2}> = tanh^2(J/T)."""
+    from tsu.models.ising import IsingChain, IsingConfig
+    n, J, T = 1_000_000, 1.0, 1.7
+    c = IsingChain(n, J=J, config=IsingConfig(temperature=T, n_burnin=200, n_sweeps=5), bias_mode="physical")
+    assert c.sparse
+    np.random.seed(2)
+    s = c.sample(4, initial_state=None).astype(np.int8)
+    assert s.shape == (4, n) and set(np.unique(s)) == {-1, 1}
+    t = np.tanh(J / T)
+    for k in range(4):
+        c1 = np.mean(s[k, :-1] * s[k, 1:])
+        c2 = np.mean(s[k, :-2] * s[k, 2:])
+        assert abs(c1 - t) < 0.004 and abs(c2 - t * t) < 0.005, (c1, c2, t)
+        assert abs(c.energy(s[k]) / n + J * t) < 0.004
+    assert abs(c.magnetization(s)) < 0.01
+    gs, e = c.find_ground_state(n_steps=60)
+    assert e / n < -0.9                              # annealed towards the ferromagnetic ground state (domains remain)

@@ -36,6 +36,7 @@ class UnsupportedError(HipError):
 
 _u8p, _i8p = C.POINTER(C.c_uint8), C.POINTER(C.c_int8)
 _u32p, _u64p, _i64p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_int64)
+_i32p = C.POINTER(C.c_int32)
 _f32p, _f64p = C.POINTER(C.c_float), C.POINTER(C.c_double)
 _vp = C.c_void_p
 
@@ -83,6 +84,13 @@ SIGNATURES = {
     "tsu_dense_anneal": (C.c_int, [_vp, _f64p, C.c_int, _i64p, C.c_uint64, C.c_uint32, C.c_uint32, _f64p, _i8p]),
     "tsu_dense_sweep_replicas": (C.c_int, [_vp, C.c_int, _f64p, C.c_int, _i8p, _u64p, _u32p, _u32p, _f64p]),
     "tsu_dense_energy": (C.c_int, [_vp, _f64p]),
+    "tsu_sparse_create": (C.c_int, [_vp, C.c_int, _i64p, _i32p, _f64p, _f64p, C.c_int, _i32p, _i32p, C.POINTER(_vp)]),
+    "tsu_sparse_destroy": (C.c_int, [_vp]),
+    "tsu_sparse_set_state": (C.c_int, [_vp, _i8p]),
+    "tsu_sparse_get_state": (C.c_int, [_vp, _i8p]),
+    "tsu_sparse_sweep": (C.c_int, [_vp, C.c_double, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32]),
+    "tsu_sparse_sample": (C.c_int, [_vp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, _i8p]),
+    "tsu_sparse_energy": (C.c_int, [_vp, _f64p, _i64p]),
     "tsu_langevin_create": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)]),
     "tsu_langevin_destroy": (C.c_int, [_vp]),
     "tsu_langevin_set_state": (C.c_int, [_vp, _f32p]),
@@ -416,6 +424,62 @@ class DenseSystem:
         e = C.c_double(0)
         self.ctx.check(self.lib.tsu_dense_energy(self.h, C.byref(e)))
         return e.value
+
+
+class SparseSystem:
+    """tsu_sparse handle: a sparse coupling graph (CSR, bit couplings incl. an optional diagonal) with a proper colouring,
+    swept one colour class at a time (K5).  ``order`` lists the sites colour by colour, ``color_offsets`` delimits the
+    colours in it.  State is {0,1} int8 in site order."""
+
+    def __init__(self, row_ptr, col_idx, values, bias, color_offsets, order, ctx=None):
+        self.ctx = ctx or Context.default()
+        self.lib = self.ctx.lib
+        rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
+        ci = np.ascontiguousarray(col_idx, dtype=np.int32)
+        va = np.ascontiguousarray(values, dtype=np.float64)
+        self.n = rp.size - 1
+        b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float64).reshape(self.n)
+        co = np.ascontiguousarray(color_offsets, dtype=np.int32)
+        od = np.ascontiguousarray(order, dtype=np.int32).reshape(self.n)
+        self.n_colors = co.size - 1
+        h = _vp()
+        self.ctx.check(self.lib.tsu_sparse_create(self.ctx.h, self.n, _ptr(rp, _i64p), _ptr(ci, _i32p), _ptr(va, _f64p),
+                                                  None if b is None else _ptr(b, _f64p), self.n_colors, _ptr(co, _i32p),
+                                                  _ptr(od, _i32p), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tsu_sparse_destroy(self.h)
+            self.h = None
+
+    def __del__(self, _finalizing=sys.is_finalizing):
+        if not _finalizing():
+            self.close()
+
+    def set_state(self, bits):
+        b = np.ascontiguousarray(bits, dtype=np.int8).reshape(self.n)
+        self.ctx.check(self.lib.tsu_sparse_set_state(self.h, _ptr(b, _i8p)))
+
+    def get_state(self):
+        out = np.empty(self.n, dtype=np.int8)
+        self.ctx.check(self.lib.tsu_sparse_get_state(self.h, _ptr(out, _i8p)))
+        return out
+
+    def sweep(self, T, n_sweeps, seed=0, sweep0=0, replica=0):
+        self.ctx.check(self.lib.tsu_sparse_sweep(self.h, float(T), int(n_sweeps), int(seed), int(sweep0), int(replica)))
+
+    def sample(self, T, n_burnin, n_sweeps, n_samples, seed=0, sweep0=0, replica=0):
+        out = np.empty((int(n_samples), self.n), dtype=np.int8)
+        self.ctx.check(self.lib.tsu_sparse_sample(self.h, float(T), int(n_burnin), int(n_sweeps), int(n_samples), int(seed),
+                                                  int(sweep0), int(replica), _ptr(out, _i8p)))
+        return out
+
+    def energy(self):
+        """(-1/2 s'Js - b's of the resident bits, sum of the spins 2b-1)."""
+        e, m = C.c_double(0), C.c_int64(0)
+        self.ctx.check(self.lib.tsu_sparse_energy(self.h, C.byref(e), C.byref(m)))
+        return e.value, m.value
 
 
 class LangevinChains:

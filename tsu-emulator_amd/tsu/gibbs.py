@@ -23,6 +23,11 @@ import numpy as np
 from . import _hip
 
 
+def _is_sparse(a) -> bool:
+    """scipy.sparse matrices / arrays select the colour-parallel sparse kernel (K5); everything else is a dense J."""
+    return hasattr(a, "tocsr") and hasattr(a, "nnz")
+
+
 @dataclass
 class GibbsConfig:
     """Reference: tsu/gibbs.py:19-36 (same fields, defaults and ValueError messages)."""
@@ -82,6 +87,7 @@ class GibbsSampler:
         self._dtype = _hip.DTYPE_F64 if coupling_dtype == "float64" else _hip.DTYPE_F32
         self._bound = None  # (content key of J, content key of bias, DenseSystem)
         self._held = None   # (J object, bias object): arrays whose device copy is reused WITHOUT a content check
+        self._bound_sparse = None  # (content key of the CSR arrays and bias, SparseSystem)
 
     # ------------------------------------------------------------------ scalar helpers (host)
     def _sigmoid(self, x: float) -> float:
@@ -119,6 +125,9 @@ class GibbsSampler:
             self._bound[2].close()
         self._bound = None
         self._held = None
+        if self._bound_sparse is not None:
+            self._bound_sparse[1].close()
+            self._bound_sparse = None
 
     def bind(self, coupling: np.ndarray, bias: Optional[np.ndarray] = None) -> "GibbsSampler":
         """Opt-in caching for hot loops: upload ``coupling`` / ``bias`` now and, until :meth:`unbind` (or a call with
@@ -185,16 +194,83 @@ class GibbsSampler:
     # ------------------------------------------------------------------ sweep-level API (GPU)
     def gibbs_sweep(self, state: np.ndarray, coupling: np.ndarray, bias: Optional[np.ndarray] = None,
                     n_sweeps: int = 1) -> np.ndarray:
-        """Reference: tsu/gibbs.py:128-162.  Returns a NEW array of the input dtype; the input is not modified."""
-        sys = self._system(coupling, bias)
+        """Reference: tsu/gibbs.py:128-162.  Returns a NEW array of the input dtype; the input is not modified.
+
+        ``coupling`` may be a ``scipy.sparse`` matrix: the sweep then runs on the colour-parallel sparse kernel, i.e. the
+        reference's sequential loop in the colour-major visiting order of a proper colouring of the graph."""
         state = np.asarray(state)
+        if _is_sparse(coupling):
+            sys = self._sparse_system(coupling, bias)
+            sys.set_state(self._as_bits(state, sys.n))
+            self._run_sparse(sys, int(n_sweeps))
+            return sys.get_state().astype(state.dtype)
+        sys = self._system(coupling, bias)
         sys.set_state(self._as_bits(state, sys.n))
         self._run_sweeps(sys, int(n_sweeps))
         return sys.get_state().astype(state.dtype)
 
+    # ------------------------------------------------------------------ sparse graphs (K5)
+    def _sparse_system(self, coupling, bias) -> "_hip.SparseSystem":
+        from .graph import canonical_csr, color_graph
+        if self.rng != "philox":
+            raise ValueError("sparse couplings run in colour-parallel order: rng must be 'philox'")
+        if self.config.update_order != "sequential":
+            raise ValueError("sparse couplings run in colour-parallel order: update_order must be 'sequential'")
+        if coupling.shape[0] != coupling.shape[1]:
+            raise ValueError("Coupling matrix must be square")
+        A = canonical_csr(coupling)
+        b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float64)
+        key = (A.shape, _content_key(A.indptr), _content_key(A.indices), _content_key(A.data), _content_key(b))
+        if self._bound_sparse is not None and self._bound_sparse[0] == key:
+            return self._bound_sparse[1]
+        if self._bound_sparse is not None:
+            self._bound_sparse[1].close()
+            self._bound_sparse = None
+        offsets, order = color_graph(A)
+        sys = _hip.SparseSystem(A.indptr, A.indices, A.data, b, offsets, order)
+        self._bound_sparse = (key, sys)
+        return sys
+
+    def _run_sparse(self, sys: "_hip.SparseSystem", n_sweeps: int):
+        if n_sweeps <= 0:
+            return
+        T = float(self.config.temperature)
+        if T <= 0:
+            raise ValueError("Temperature must be positive")
+        sys.sweep(T, n_sweeps, seed=self._philox_seed(), sweep0=self._sweep_counter)
+        self._sweep_counter += n_sweeps
+
+    def _sample_sparse(self, coupling, bias, n_samples, burnin, initial_state, dtype=int) -> np.ndarray:
+        n_bits = coupling.shape[0]
+        sys = self._sparse_system(coupling, bias)
+        burnin = burnin if burnin is not None else self.config.n_burnin
+        state = np.asarray(initial_state).copy() if initial_state is not None else np.random.randint(0, 2, size=n_bits)
+        sys.set_state(self._as_bits(state, n_bits))
+        T = float(self.config.temperature)
+        if T <= 0:
+            raise ValueError("Temperature must be positive")
+        n_sweeps = int(self.config.n_sweeps)
+        samples = np.zeros((n_samples, n_bits), dtype=dtype)
+        chunk = max(1, min(int(n_samples), (1 << 30) // max(1, n_bits)))  # <= 1 GiB of recorded states per call
+        done, burn = 0, int(burnin)
+        if n_samples == 0:
+            self._run_sparse(sys, burn)
+        while done < n_samples:
+            m = min(chunk, n_samples - done)
+            samples[done:done + m] = sys.sample(T, burn, n_sweeps, m, seed=self._philox_seed(), sweep0=self._sweep_counter)
+            self._sweep_counter += burn + m * n_sweeps
+            self.sample_count += m
+            done += m
+            burn = 0
+        return samples
+
     def sample_boltzmann(self, coupling: np.ndarray, bias: Optional[np.ndarray] = None, n_samples: int = 1000,
                          burnin: Optional[int] = None, initial_state: Optional[np.ndarray] = None) -> np.ndarray:
         """Reference: tsu/gibbs.py:164-213.  Returns ``(n_samples, n_bits)`` int array of 0/1."""
+        if _is_sparse(coupling):
+            if coupling.shape[0] != coupling.shape[1]:
+                raise ValueError("Coupling matrix must be square")
+            return self._sample_sparse(coupling, bias, n_samples, burnin, initial_state)
         coupling = np.asarray(coupling)
         n_bits = coupling.shape[0]
         if coupling.shape != (n_bits, n_bits):
@@ -250,6 +326,10 @@ class GibbsSampler:
 
     def compute_energy(self, state: np.ndarray, coupling: np.ndarray, bias: Optional[np.ndarray] = None) -> float:
         """Reference: tsu/gibbs.py:215-236 -- E = -1/2 s^T J s - b^T s (device matvec + reduction)."""
+        if _is_sparse(coupling):
+            sys = self._sparse_system(coupling, bias)
+            sys.set_state(self._as_bits(state, sys.n))
+            return float(sys.energy()[0])
         sys = self._system(coupling, bias)
         sys.set_state(self._as_bits(state, sys.n))
         return float(sys.energy())
@@ -354,6 +434,8 @@ class GibbsSampler:
                             T_final: float = 0.1, n_steps: int = 1000,
                             cooling_schedule: str = "exponential") -> Tuple[np.ndarray, float]:
         """Reference: tsu/gibbs.py:340-393 (mutates ``self.config.temperature`` in place, as the reference does)."""
+        if _is_sparse(coupling):
+            return self._anneal_sparse(coupling, bias, T_initial, T_final, n_steps, cooling_schedule)
         coupling = np.asarray(coupling)
         n_bits = coupling.shape[0]
         state = np.random.randint(0, 2, size=n_bits)
@@ -414,6 +496,27 @@ class GibbsSampler:
                     best_energy = energy
                     best_state = cand
         return best_state, best_energy
+
+    def _anneal_sparse(self, coupling, bias, T_initial, T_final, n_steps, cooling_schedule):
+        """simulated_annealing (gibbs.py:340-393) on a sparse graph: one colour-parallel sweep per temperature, the
+        energy of every state by the device reduction, the best state kept."""
+        n_bits = coupling.shape[0]
+        state = np.random.randint(0, 2, size=n_bits)
+        if cooling_schedule == "exponential":
+            temps = [T_initial * (T_final / T_initial) ** (step / n_steps) for step in range(n_steps)]
+        else:
+            temps = [T_initial + (T_final - T_initial) * step / n_steps for step in range(n_steps)]
+        sys = self._sparse_system(coupling, bias)
+        sys.set_state(self._as_bits(state, n_bits))
+        best_state, best_energy = state.copy(), sys.energy()[0]
+        for T in temps:
+            self.config.temperature = T
+            self._run_sparse(sys, 1)
+            energy = sys.energy()[0]
+            if energy < best_energy:
+                best_energy = energy
+                best_state = sys.get_state().astype(state.dtype)
+        return best_state, float(best_energy)
 
     _ANNEAL_HOST_ENERGY_MAX = 512  # systems up to this size: energies of the recorded states on the host
 

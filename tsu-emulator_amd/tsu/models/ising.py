@@ -47,14 +47,30 @@ def _mode_id(bias_mode: str) -> int:
 
 
 class IsingModel:
-    """General Ising model on an arbitrary graph.  Reference: tsu/models/ising.py:39-262."""
+    """General Ising model on an arbitrary graph.  Reference: tsu/models/ising.py:39-262.
 
-    def __init__(self, n_spins: int, config: Optional[IsingConfig] = None, *, bias_mode: str = "compat"):
+    ``graph="dense"`` keeps the coupling matrix as the reference does (an N x N array, sites visited in raster order on
+    the dense kernel K2).  ``graph="sparse"`` keeps only the couplings that were set (``scipy.sparse``) and samples on
+    the colour-parallel sparse kernel K5 -- the sequential loop of gibbs.py:128-162 in the colour-major visiting order of
+    a proper colouring -- which is what makes a 10^6-site chain possible (its dense J would be 8 TB).  ``"auto"``
+    (default): sparse above ``DENSE_LIMIT`` sites, dense below."""
+
+    DENSE_LIMIT = 16384  # largest N for which a dense J is kept / may be materialised (2 GiB of float64)
+
+    def __init__(self, n_spins: int, config: Optional[IsingConfig] = None, *, bias_mode: str = "compat", graph: str = "auto"):
         _mode_id(bias_mode)
+        if graph not in ("auto", "dense", "sparse"):
+            raise ValueError("graph must be 'auto', 'dense' or 'sparse'")
         self.n_spins = n_spins
         self.config = config or IsingConfig()
         self.bias_mode = bias_mode
-        self._J = np.zeros((n_spins, n_spins))
+        self.sparse = graph == "sparse" or (graph == "auto" and n_spins > self.DENSE_LIMIT)
+        if self.sparse:
+            import scipy.sparse as sp
+            self._J = None
+            self._Jsp = sp.csr_matrix((n_spins, n_spins), dtype=np.float64)
+        else:
+            self._J = np.zeros((n_spins, n_spins))
         self.h = np.ones(n_spins) * self.config.external_field
         gibbs_config = GibbsConfig(temperature=self.config.temperature, n_burnin=self.config.n_burnin,
                                    n_sweeps=self.config.n_sweeps)
@@ -63,16 +79,40 @@ class IsingModel:
     # ``J`` is a plain attribute in the reference; a property here so that IsingGrid can build it lazily
     @property
     def J(self) -> np.ndarray:
+        if getattr(self, "sparse", False):
+            if self.n_spins > self.DENSE_LIMIT:
+                raise MemoryError(f"dense J for {self.n_spins} spins would need {8 * self.n_spins ** 2 / 2 ** 30:.0f} GiB; "
+                                  "the sparse kernel does not need it (see .J_sparse)")
+            dense = self._Jsp.toarray()
+            dense.setflags(write=False)  # a copy: edits would be lost -- use set_coupling()
+            return dense
         return self._J
 
     @J.setter
     def J(self, value):
-        self._J = np.asarray(value, dtype=float)
+        if getattr(self, "sparse", False):
+            import scipy.sparse as sp
+            self._Jsp = sp.csr_matrix(value, dtype=np.float64)
+            self.sampler.invalidate()
+        else:
+            self._J = np.asarray(value, dtype=float)
+
+    @property
+    def J_sparse(self):
+        """The coupling matrix as ``scipy.sparse`` CSR (sparse models: the stored graph; dense models: a conversion)."""
+        import scipy.sparse as sp
+        return self._Jsp.tocsr() if self.sparse else sp.csr_matrix(self.J)
 
     def set_coupling(self, i: int, j: int, strength: float):
         """Reference: ising.py:77-86 (symmetric assignment, not accumulation)."""
-        self.J[i, j] = strength
-        self.J[j, i] = strength
+        if self.sparse:
+            if not hasattr(self._Jsp, "rows"):       # CSR -> LIL once: cheap element assignment
+                self._Jsp = self._Jsp.tolil()
+            self._Jsp[i, j] = strength
+            self._Jsp[j, i] = strength
+        else:
+            self.J[i, j] = strength
+            self.J[j, i] = strength
         self.sampler.invalidate()
 
     def set_external_field(self, field: np.ndarray):
@@ -84,7 +124,10 @@ class IsingModel:
     def energy(self, state: np.ndarray) -> float:
         """Reference: ising.py:99-117 -- E(s) = -1/2 s'Js - h's."""
         state = np.asarray(state)
-        interaction_energy = -0.5 * state.dot(self.J).dot(state)
+        if self.sparse:
+            interaction_energy = -0.5 * state.dot(self._Jsp.tocsr().dot(state))
+        else:
+            interaction_energy = -0.5 * state.dot(self.J).dot(state)
         field_energy = -self.h.dot(state)
         return interaction_energy + field_energy
 
@@ -98,13 +141,16 @@ class IsingModel:
 
     def _get_bit_coupling(self) -> np.ndarray:
         """Reference: ising.py:127-138 -- J_bit = 4 J."""
+        if self.sparse:
+            return (4 * self._Jsp).tocsr()
         return 4 * self.J
 
     def _get_bit_bias(self) -> np.ndarray:
         """Reference: ising.py:140-148 (``compat``: verbatim, including its sign), or the corrected conversion."""
+        rowsum = np.asarray(self._Jsp.sum(axis=1)).ravel() if self.sparse else np.sum(self.J, axis=1)
         if self.bias_mode == "compat":
-            return -2 * self.h + 2 * np.sum(self.J, axis=1)
-        return 2 * self.h - 2 * np.sum(self.J, axis=1)
+            return -2 * self.h + 2 * rowsum
+        return 2 * self.h - 2 * rowsum
 
     def sample(self, n_samples: int = 1000, initial_state: Optional[np.ndarray] = None) -> np.ndarray:
         """Reference: ising.py:150-181 -- (n_samples, n_spins) array of +-1."""
@@ -147,11 +193,17 @@ class IsingModel:
 class IsingChain(IsingModel):
     """1-D chain with open ends.  Reference: ising.py:265-304."""
 
-    def __init__(self, n_spins: int, J: float = 1.0, config: Optional[IsingConfig] = None, *, bias_mode: str = "compat"):
-        super().__init__(n_spins, config, bias_mode=bias_mode)
-        for i in range(n_spins - 1):
-            self._J[i, i + 1] = J
-            self._J[i + 1, i] = J
+    def __init__(self, n_spins: int, J: float = 1.0, config: Optional[IsingConfig] = None, *, bias_mode: str = "compat",
+                 graph: str = "auto"):
+        super().__init__(n_spins, config, bias_mode=bias_mode, graph=graph)
+        if self.sparse:
+            import scipy.sparse as sp
+            off = np.full(max(n_spins - 1, 0), float(J))
+            self._Jsp = sp.diags([off, off], [1, -1], shape=(n_spins, n_spins), format="csr", dtype=np.float64)
+        else:
+            for i in range(n_spins - 1):
+                self._J[i, i + 1] = J
+                self._J[i + 1, i] = J
 
     def visualize(self, state: np.ndarray, title: str = "Ising Chain"):
         """Reference: ising.py:288-304."""
@@ -206,7 +258,8 @@ class IsingGrid(IsingModel):
         self.bias_mode = bias_mode
         self.periodic = periodic
         self.coupling = float(J)
-        self._J = None          # built on first access
+        self.sparse = False     # the lattice has its own kernel (K1); the dense view is built on first access
+        self._J = None
         self._custom = False    # set_coupling() was called / J was edited: no longer a uniform lattice
         self._J_key = None
         self.h = np.ones(self.n_spins) * self.config.external_field
