@@ -343,8 +343,35 @@ def g10():
     save("g10_equilibrium", **arrs)
 
 
+# ---------------------------------------------------------------- G11: the reference's sampling benchmark (f4)
+def g11():
+    """tsu.benchmarks.sampling.SamplingBenchmark(seed=42).run_all_benchmarks(quick) of the reference, quick and full mode:
+    the quality metrics of every trial (the timing fields are the reference's CPU and are stored for information only)."""
+    import contextlib
+    import io
+    from tsu.benchmarks.sampling import SamplingBenchmark
+    arrs = {}
+    for quick in (True, False):
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = SamplingBenchmark(seed=42).run_all_benchmarks(quick=quick)
+        for name, r in res.items():
+            key = f"{'quick' if quick else 'full'}_{name}"
+            arrs[key + "_n_samples"] = r.n_samples
+            arrs[key + "_n_trials"] = r.n_trials
+            arrs[key + "_distribution"] = np.array(r.distribution_name)
+            arrs[key + "_ks_statistics"] = np.array(r.ks_statistics)
+            arrs[key + "_ks_pvalues"] = np.array(r.ks_pvalues)
+            arrs[key + "_kl_divergences"] = np.array(r.kl_divergences)
+            arrs[key + "_effective_sample_sizes"] = np.array(r.effective_sample_sizes)
+            arrs[key + "_samples_per_second"] = np.array(r.samples_per_second)
+            summ = r.summary()
+            arrs[key + "_summary_keys"] = np.array(sorted(summ.keys()))
+            print(key, "KL", np.mean(r.kl_divergences), "ESS", np.mean(r.effective_sample_sizes), "rate", np.mean(r.samples_per_second))
+    save("g11_sampling_benchmark", **arrs)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
-    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10):
+    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10, g11):
         if not only or fn.__name__ in only:
             fn()
