@@ -16,6 +16,7 @@
 //   instruction; only an exact tie of the top 16 bits (2^-16 per site) evaluates the low half.
 #include "ising2d.h"
 
+#include <type_traits>
 #include <vector>
 
 typedef short v2s __attribute__((ext_vector_type(2)));
@@ -121,8 +122,8 @@ static __device__ __forceinline__ u32x4 philox_vk(uint32_t c0, uint32_t c1, uint
 }
 
 struct Rows2Ctx {
-    const uint64_t* Ps;
-    uint64_t* Pd;
+    const void* Ps;  // source / destination colour plane (uint64 octets, or uint32 octets in the nibble form)
+    void* Pd;
     const uint64_t* s_thr;
     int tr_lo, npairs;   // first tile row of the half-sweep's range, number of row pairs
     int rgf;             // global row of tile row tr_lo (wrapped)
@@ -279,6 +280,73 @@ static __device__ __forceinline__ void sweep_pairs(const Rows2Ctx& c, const Phil
     }
 }
 
+
+// ================================================================== nibble planes (NIB)
+// The same update with the colour planes kept at 4 bits per site instead of 8: an octet is ONE dword, site j < 4 in the
+// low nibble of byte j, site j >= 4 in the high nibble of byte j - 4 (so that `x & 0x0F0F0F0F` and `(x >> 4) & 0x0F0F0F0F`
+// are the byte-per-site halves the threshold look-up wants).  Neighbour counts (<= 4) are summed nibble-wise with plain
+// dword adds -- half the adds of the byte form -- and only the count is widened to bytes.  Half the LDS per site: a
+// 512 x 512 tile (+ halo) fits one CU, which makes 8192^2 tile-resident and halves the halo work of the big lattices.
+// Periodic lattices whose width is a multiple of 16 only (no OPEN / SEAM forms).
+static __device__ __forceinline__ uint32_t nib_shift_next(uint32_t X, uint32_t N) {
+    // S_j = X_{j+1}; site 3 <- site 4 (high nibble of byte 0), site 7 <- site 0 of the next octet N
+    const uint32_t hi = (N << 4) | __builtin_amdgcn_ubfe(X, 4u, 4u);
+    return __builtin_amdgcn_alignbit(hi, X, 8);
+}
+static __device__ __forceinline__ uint32_t nib_shift_prev(uint32_t X, uint32_t M) {
+    // S_j = X_{j-1}; site 4 <- site 3 (low nibble of byte 3), site 0 <- site 7 of the previous octet M
+    const uint32_t w = ((X << 4) & 0x10000000u) | (M >> 4);
+    return __builtin_amdgcn_alignbit(X, w, 24);
+}
+static __device__ __forceinline__ uint32_t nib_pack(const u32x4& d) {
+    const uint64_t f = pack_flags(d);
+    return (uint32_t)f | ((uint32_t)(f >> 32) << 4);
+}
+
+template <int NO, int P0, bool EDGE>
+static __device__ __forceinline__ void sweep_pairs_nib(const Rows2Ctx& c, const PhiloxKeys& K, int al, int oct, uint32_t cq, int RL) {
+    const char* const ps0 = reinterpret_cast<const char*>(c.Ps);
+    const int d_off = (int)(reinterpret_cast<const char*>(c.Pd) - ps0);
+    const int off_end = (c.tr_lo + 2 * c.npairs) * NO * 4;
+    const int off_step = 2 * RL * NO * 4;
+    int off = ((c.tr_lo + 2 * al) * NO + oct) * 4;
+    int rg = c.rgf + 2 * al;
+#pragma unroll 1
+    for (; off < off_end; off += off_step, rg += 2 * RL) {
+        asm volatile("" : "+v"(off), "+v"(rg));
+        const char* ps = ps0 + off;
+        const uint32_t R0 = *reinterpret_cast<const uint32_t*>(ps - NO * 4), R1 = *reinterpret_cast<const uint32_t*>(ps);
+        const uint32_t R2 = *reinterpret_cast<const uint32_t*>(ps + NO * 4), R3 = *reinterpret_cast<const uint32_t*>(ps + 2 * NO * 4);
+        const uint32_t A0 = *reinterpret_cast<const uint32_t*>(ps + (P0 ? 4 : -4));           // row a: next octet if P0, else the previous one
+        const uint32_t A1 = *reinterpret_cast<const uint32_t*>(ps + NO * 4 + (P0 ? -4 : 4));  // row b: the other side
+        __builtin_amdgcn_sched_barrier(0);
+        int rga = rg, rgb = rg + 1;
+        if (EDGE) {
+            if (rga >= c.total_rows) rga -= c.total_rows;
+            if (rgb >= c.total_rows) rgb -= c.total_rows;
+        }
+        const u32x4 w0 = philox_vk(cq, (uint32_t)rga, c.hs, c.tag_hi, K);
+        const u32x4 w1 = philox_vk(cq, (uint32_t)rgb, c.hs, c.tag_hi, K);
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t Sa = P0 ? nib_shift_next(R1, A0) : nib_shift_prev(R1, A0);
+        const uint32_t Sb = P0 ? nib_shift_prev(R2, A1) : nib_shift_next(R2, A1);
+        const uint32_t mid = R1 + R2;  // shared by both rows' vertical + centre sums
+        const uint32_t cnt0 = R0 + mid + Sa, cnt1 = R3 + mid + Sb;
+        const uint32_t cnt0l = cnt0 & 0x0F0F0F0Fu, cnt0h = (cnt0 >> 4) & 0x0F0F0F0Fu;
+        const uint32_t cnt1l = cnt1 & 0x0F0F0F0Fu, cnt1h = (cnt1 >> 4) & 0x0F0F0F0Fu;
+        u32x4 d0 = compare_octet(w0, cnt0l, cnt0h, c.tblH0, c.tblH1, c.tblL0, c.tblL1);
+        u32x4 d1 = compare_octet(w1, cnt1l, cnt1h, c.tblH0, c.tblH1, c.tblL0, c.tblL1);
+        const uint32_t mn = minu16(minu16(minu16(d0.x, d0.y), minu16(d0.z, d0.w)), minu16(minu16(d1.x, d1.y), minu16(d1.z, d1.w)));
+        if (__builtin_expect(((mn & 0xFFFFu) == 0) | ((mn >> 16) == 0), 0)) {
+            if (has_zero_field(d0)) d0 = resolve_ties(d0, w0, cnt0l, cnt0h, c.s_thr, cq, (uint32_t)rga, c.hs, c.tag_lo, c.k0, c.k1, 0);
+            if (has_zero_field(d1)) d1 = resolve_ties(d1, w1, cnt1l, cnt1h, c.s_thr, cq, (uint32_t)rgb, c.hs, c.tag_lo, c.k0, c.k1, 0);
+        }
+        char* pd = const_cast<char*>(ps) + d_off;
+        *reinterpret_cast<uint32_t*>(pd) = nib_pack(d0);
+        *reinterpret_cast<uint32_t*>(pd + NO * 4) = nib_pack(d1);
+    }
+}
+
 // one tile: HBM -> LDS planes, 2k half-sweeps, interior -> HBM (the other buffer)
 // Tile-resident generations (RESIDENT): when every tile of the lattice has its own workgroup on the chip at the same
 // time, a tile stays in LDS for many generations of k sweeps; after each generation it publishes the 2k interior rows
@@ -304,7 +372,7 @@ struct ResidentParams {
     long long* dbg;  // TSU_K1_VERBOSE=2: wall_clock64 ticks of tile 0 spent in [sweeps, publish, wait, fetch]
 };
 
-template <int HT, int WO, int THREADS, bool OPEN = false, bool RESIDENT = false>
+template <int HT, int WO, int THREADS, bool OPEN = false, bool RESIDENT = false, bool NIB = false>
 static __device__ __forceinline__ void tile_body(const TiledParams& p, const int8_t* __restrict__ src, int8_t* __restrict__ dst,
                                                  const int k, const uint32_t sweep0, const int tx, const int ty, uint64_t* lds,
                                                  const PhiloxKeys& K, const ResidentParams* R = nullptr) {
@@ -317,9 +385,12 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
     // partial iteration occupies the fewest waves and those are consecutive, i.e. spread round-robin over the four
     // SIMDs (+5 % on 4096^2 against the smallest lane count that reaches the same iteration count).
     constexpr int RL = RLMAX;
-    uint64_t* plane0 = lds + 1;
-    uint64_t* plane1 = plane0 + TR * NO;
-    uint64_t* s_thr = plane1 + TR * NO + NO + 1;  // one spare row: the pair loop reads row idx + 2 NO of the last pair
+    static_assert(!(NIB && OPEN), "the nibble planes are built for periodic lattices only");
+    using E = typename std::conditional<NIB, uint32_t, uint64_t>::type;  // one octet of a colour plane
+    E* plane0 = reinterpret_cast<E*>(lds + 1);
+    E* plane1 = plane0 + TR * NO;
+    // one spare row: the pair loop reads row idx + 2 NO of the last pair (rounded up to the uint64 grid)
+    uint64_t* s_thr = reinterpret_cast<uint64_t*>((reinterpret_cast<uintptr_t>(plane1 + TR * NO + NO + 1) + 7u) & ~(uintptr_t)7u);
     const int tid = threadIdx.x;
     if (tid < 25) s_thr[tid] = p.thr[tid];
 
@@ -378,8 +449,13 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
                     }
                     const int idx = tr * NO + oct;
                     const int gpar = (int)((p.row0 + Rb + tr) & 1);  // colour of the even columns of this row
-                    (gpar ? plane1 : plane0)[idx] = ev;
-                    (gpar ? plane0 : plane1)[idx] = od;
+                    if (NIB) {
+                        (gpar ? plane1 : plane0)[idx] = (E)((uint32_t)ev | ((uint32_t)(ev >> 32) << 4));
+                        (gpar ? plane0 : plane1)[idx] = (E)((uint32_t)od | ((uint32_t)(od >> 32) << 4));
+                    } else {
+                        (gpar ? plane1 : plane0)[idx] = (E)ev;
+                        (gpar ? plane0 : plane1)[idx] = (E)od;
+                    }
                 }
             }
         }
@@ -452,7 +528,15 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
         c.rgf = rgf;
         const int par0 = (int)((p.row0 + Rb + c.tr_lo + kappa) & 1);
         if (al < RL) {
-            if (OPEN) {
+            if (NIB) {
+                if (edge) {
+                    if (par0) sweep_pairs_nib<NO, 1, true>(c, K, al, oct, cq, RL);
+                    else sweep_pairs_nib<NO, 0, true>(c, K, al, oct, cq, RL);
+                } else {
+                    if (par0) sweep_pairs_nib<NO, 1, false>(c, K, al, oct, cq, RL);
+                    else sweep_pairs_nib<NO, 0, false>(c, K, al, oct, cq, RL);
+                }
+            } else if (OPEN) {
                 if (par0) sweep_pairs<NO, 1, false, true>(c, K, al, oct, cq, RL);
                 else sweep_pairs<NO, 0, false, true>(c, K, al, oct, cq, RL);
             } else if (seam) {
@@ -482,20 +566,21 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
         // round trip that is repeated only for the elements that were not there yet.  (A slot is rewritten every second
         // generation and neighbours are never more than one generation apart, so a stale element always carries another
         // number; the host clears the buffer when the numbering restarts or the strip layout changes.)
+        // (nibble planes: an element is the octet's dword, the number sits above it in bits 32..45)
         const uint32_t G = R->gen0 + (uint32_t)gen;
-        const uint64_t tag = ((uint64_t)(G & 0x7Fu) << 1) | ((uint64_t)((G >> 7) & 0x7Fu) << 9);
-        constexpr uint64_t TAG_MASK = 0xFEFEull, FLAG_MASK = 0x0101010101010101ull;
+        const uint64_t tag = NIB ? ((uint64_t)G << 32) : (((uint64_t)(G & 0x7Fu) << 1) | ((uint64_t)((G >> 7) & 0x7Fu) << 9));
+        constexpr uint64_t TAG_MASK = NIB ? 0xFFFFFFFF00000000ull : 0xFEFEull, FLAG_MASK = NIB ? 0x11111111ull : 0x0101010101010101ull;
         for (int i = tid; i < 2 * n_tb; i += THREADS) {
             const int pl = i / n_tb, rem = i - pl * n_tb, r = rem / WO, o = rem - r * WO;
-            const uint64_t* P = pl ? plane1 : plane0;
-            xst(mine + i, P[(2 * k + r) * NO + 1 + o] | tag);           // TOP: first 2k interior rows
-            xst(mine + 2 * n_tb + i, P[(H + r) * NO + 1 + o] | tag);    // BOTTOM: last 2k interior rows
+            const E* P = pl ? plane1 : plane0;
+            xst(mine + i, (uint64_t)P[(2 * k + r) * NO + 1 + o] | tag);           // TOP: first 2k interior rows
+            xst(mine + 2 * n_tb + i, (uint64_t)P[(H + r) * NO + 1 + o] | tag);    // BOTTOM: last 2k interior rows
         }
         for (int i = tid; i < 2 * n_lr; i += THREADS) {
             const int pl = i / n_lr, r = i - pl * n_lr;
-            const uint64_t* P = pl ? plane1 : plane0;
-            xst(mine + 4 * n_tb + i, P[(2 * k + r) * NO + 1] | tag);             // LEFT: first interior octet
-            xst(mine + 4 * n_tb + 2 * n_lr + i, P[(2 * k + r) * NO + WO] | tag); // RIGHT: last interior octet
+            const E* P = pl ? plane1 : plane0;
+            xst(mine + 4 * n_tb + i, (uint64_t)P[(2 * k + r) * NO + 1] | tag);             // LEFT: first interior octet
+            xst(mine + 4 * n_tb + 2 * n_lr + i, (uint64_t)P[(2 * k + r) * NO + WO] | tag); // RIGHT: last interior octet
         }
         RES_MARK(1);
         const int txl = tx == 0 ? tiles_x - 1 : tx - 1, txr = tx == tiles_x - 1 ? 0 : tx + 1;
@@ -516,7 +601,7 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
         // a thread is issued before the first is looked at, and unconditionally: a neighbour index always names a real
         // tile, a missing neighbour's value is neither checked nor stored.
         constexpr int FI = (2 * 2 * 8 * NO + THREADS - 1) / THREADS;   // k <= 8
-        constexpr int TH_MAX = 160 * 1024 / 8 / (2 * NO) - 32;         // tallest (stretched slab) tile whose planes fit the CU's LDS
+        constexpr int TH_MAX = 160 * 1024 / (int)sizeof(E) / (2 * NO) - 32;  // tallest (stretched slab) tile whose planes fit the CU's LDS
         constexpr int SI = (2 * TH_MAX + THREADS - 1) / THREADS;
         const uint64_t* au[FI];
         const uint64_t* ad[FI];
@@ -571,9 +656,9 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
             const int i = tid + it * THREADS;
             if (i < 2 * 2 * k * NO) {
                 const int pl = i / (2 * k * NO), rem = i - pl * (2 * k * NO), r = rem / NO, o = rem - r * NO;
-                uint64_t* P = pl ? plane1 : plane0;
-                if (nu[it]) P[r * NO + o] = vu[it] & FLAG_MASK;
-                if (nd[it]) P[(2 * k + H + r) * NO + o] = vd[it] & FLAG_MASK;
+                E* P = pl ? plane1 : plane0;
+                if (nu[it]) P[r * NO + o] = (E)(vu[it] & FLAG_MASK);
+                if (nd[it]) P[(2 * k + H + r) * NO + o] = (E)(vd[it] & FLAG_MASK);
             }
         }
 #pragma unroll
@@ -581,9 +666,9 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
             const int i = tid + it * THREADS;
             if (i < 2 * n_lr) {
                 const int pl = i / n_lr, r = i - pl * n_lr;
-                uint64_t* P = pl ? plane1 : plane0;
-                if (nl[it]) P[(2 * k + r) * NO] = vl[it] & FLAG_MASK;
-                if (nr[it]) P[(2 * k + r) * NO + NO - 1] = vr[it] & FLAG_MASK;
+                E* P = pl ? plane1 : plane0;
+                if (nl[it]) P[(2 * k + r) * NO] = (E)(vl[it] & FLAG_MASK);
+                if (nr[it]) P[(2 * k + r) * NO + NO - 1] = (E)(vr[it] & FLAG_MASK);
             }
         }
         __syncthreads();
@@ -603,7 +688,11 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
             const int rl = r0 + hr;
             if (rl < p.r_end) {
                 const int li = (2 * k + hr) * NO + oct;
-                const uint64_t ev = (gpar ? plane1 : plane0)[li], od = (gpar ? plane0 : plane1)[li];
+                uint64_t ev = (gpar ? plane1 : plane0)[li], od = (gpar ? plane0 : plane1)[li];
+                if (NIB) {  // nibble octet -> byte-per-site flags
+                    ev = (ev & 0x01010101ull) | (((ev >> 4) & 0x01010101ull) << 32);
+                    od = (od & 0x01010101ull) | (((od >> 4) & 0x01010101ull) << 32);
+                }
                 // up flag -> spin byte: 1 -> 0x01, 0 -> 0xFF
                 const uint32_t e0 = perm(0u, 0x000001FFu, (uint32_t)ev), e1 = perm(0u, 0x000001FFu, (uint32_t)(ev >> 32));
                 const uint32_t o0 = perm(0u, 0x000001FFu, (uint32_t)od), o1 = perm(0u, 0x000001FFu, (uint32_t)(od >> 32));
@@ -623,11 +712,11 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
     }
 }
 
-template <int H, int WO, int THREADS, int MINW = 1, bool OPEN = false>
+template <int H, int WO, int THREADS, int MINW = 1, bool OPEN = false, bool NIB = false>
 __global__ __launch_bounds__(THREADS, MINW) void k1_tiled2(TiledParams p) {
     extern __shared__ uint64_t lds[];
     const PhiloxKeys K = make_keys(p.k0, p.k1);
-    tile_body<H, WO, THREADS, OPEN>(p, p.src, p.dst, p.k, p.sweep0, blockIdx.x % p.tiles_x,
+    tile_body<H, WO, THREADS, OPEN, false, NIB>(p, p.src, p.dst, p.k, p.sweep0, blockIdx.x % p.tiles_x,
                                     p.ty_first + (blockIdx.x / p.tiles_x) * p.ty_stride, lds, K);
 }
 
@@ -637,11 +726,11 @@ struct ResidentLaunch {
     ResidentParams r;
 };
 
-template <int H, int WO, int THREADS, int MINW = 1, bool OPEN = false>
+template <int H, int WO, int THREADS, int MINW = 1, bool OPEN = false, bool NIB = false>
 __global__ __launch_bounds__(THREADS, MINW) void k1_resident(ResidentLaunch P) {
     extern __shared__ uint64_t lds[];
     const PhiloxKeys K = make_keys(P.t.k0, P.t.k1);
-    tile_body<H, WO, THREADS, OPEN, true>(P.t, P.t.src, P.t.dst, P.t.k, P.t.sweep0, blockIdx.x % P.t.tiles_x, blockIdx.x / P.t.tiles_x,
+    tile_body<H, WO, THREADS, OPEN, true, NIB>(P.t, P.t.src, P.t.dst, P.t.k, P.t.sweep0, blockIdx.x % P.t.tiles_x, blockIdx.x / P.t.tiles_x,
                                           lds, K, &P.r);
 }
 
@@ -655,11 +744,20 @@ struct TileVariant {
     void (*resident)(ResidentLaunch);  // tile-resident multi-generation form (nullptr: not built for this shape)
     void (*open)(TiledParams);       // open-boundary form (nullptr: not built for this shape)
     void (*resident_open)(ResidentLaunch);
+    int nib;                         // colour planes at 4 bits per site (periodic lattices, width a multiple of 16)
+    int per_cu;                      // workgroups of this shape one CU is meant to hold (LDS share of a stretched slab tile)
 };
+
+// LDS of one workgroup: guard octet, two colour planes of TR x NO octets (+ one spare row), 25 thresholds
+size_t tile_lds_bytes(const TileVariant& tv, int TR) {
+    const size_t es = tv.nib ? 4 : 8, NO = (size_t)tv.WO + 2;
+    return 8 + (((size_t)2 * TR * NO + NO + 1) * es + 7) / 8 * 8 + 8 + 25 * sizeof(uint64_t);
+}
 // the tile shapes the chooser (pick_variant) can reach.  Round 1's table had 32 entries, 24 of them reachable only through
 // the TSU_TILE_VARIANT development switch; numbers quoted in profiles/r01_* map as 6 -> 0, 8 -> 1, 9 -> 2, 22 -> 3, 23 -> 4,
 // 25 -> 5, 26 -> 6, 27 -> 7
-enum { V_64x512_T512 = 0, V_128x512_T512, V_128x512_T1024, V_256x512_T1024, V_128x256_T1024, V_64x512_T1024, V_64x256_T1024, V_32x256_T1024 };
+enum { V_64x512_T512 = 0, V_128x512_T512, V_128x512_T1024, V_256x512_T1024, V_128x256_T1024, V_64x512_T1024, V_64x256_T1024, V_32x256_T1024,
+       V_N512x512_T1024, V_N256x512_T512 };
 const TileVariant kVariants[] = {
     {64, 32, 512, k1_tiled2<64, 32, 512>, k1_resident<64, 32, 512>, k1_tiled2<64, 32, 512, 1, true>},
     {128, 32, 512, k1_tiled2<128, 32, 512>, k1_resident<128, 32, 512>, k1_tiled2<128, 32, 512, 1, true>},
@@ -669,6 +767,9 @@ const TileVariant kVariants[] = {
     {64, 32, 1024, k1_tiled2<64, 32, 1024>, k1_resident<64, 32, 1024>, k1_tiled2<64, 32, 1024, 1, true>, k1_resident<64, 32, 1024, 1, true>},
     {64, 16, 1024, k1_tiled2<64, 16, 1024>, k1_resident<64, 16, 1024>, k1_tiled2<64, 16, 1024, 1, true>, k1_resident<64, 16, 1024, 1, true>},
     {32, 16, 1024, k1_tiled2<32, 16, 1024>, k1_resident<32, 16, 1024>, k1_tiled2<32, 16, 1024, 1, true>, k1_resident<32, 16, 1024, 1, true>},
+    // nibble planes: 512 x 512 sites per CU (148 KB) -- 8192^2 tile-resident; 256 x 512, two workgroups per CU, for what is larger still
+    {512, 32, 1024, k1_tiled2<512, 32, 1024, 4, false, true>, k1_resident<512, 32, 1024, 4, false, true>, nullptr, nullptr, 1, 1},
+    {256, 32, 512, k1_tiled2<256, 32, 512, 4, false, true>, nullptr, nullptr, nullptr, 1, 2},
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -712,6 +813,21 @@ int pick_variant(const tsu_ising2d* L) {
         else if (n128 <= 2 * cus && n256 <= cus && 10 * n256 >= 7 * cus) v = V_256x512_T1024;
         else v = V_128x512_T512;
         if (L->rows < 256) v = V_64x512_T512;
+        // Nibble planes (whole periodic lattices, width a multiple of 16): a lattice of exactly one 512 x 512 tile per CU
+        // (8192^2 on 256 CUs) stays resident in LDS; larger lattices take 256 x 512 tiles, two workgroups per CU, 8 sweeps
+        // per launch (half the halo rows of the 128-row byte tiles and fewer stage/store passes)
+        static int use_nib = -1;
+        if (use_nib < 0) {
+            const char* e = getenv("TSU_K1_NIBBLE");
+            use_nib = e ? atoi(e) : 1;
+        }
+        const bool nib_ok = use_nib && L->periodic && L->cols % 16 == 0 && L->ghost == 0 && L->total_rows == L->rows;
+        if (nib_ok && n128 > 2 * cus) {
+            const int nch_ = L->cols / 16;
+            const long long n512 = (long long)(L->rows / 512) * (nch_ / 32);
+            if (L->rows % 512 == 0 && nch_ % 32 == 0 && n512 <= cus && 2 * n512 > cus) v = V_N512x512_T1024;
+            else if (L->rows >= 512) v = V_N256x512_T512;
+        }
         // Lattices that give every CU at most one tile: the tile shape that finishes a generation of 8 sweeps soonest.
         // Model fitted to measurements (4096^2, 2048^2, 1024^2, 4096 x 8192, open 1000^2; profiles/r01_k1_experiments.txt):
         // a half-sweep costs 0.25 us + 0.225 us per wave-iteration of the busiest SIMD; between generations the strip
@@ -777,7 +893,7 @@ int tsu_ising2d_tiled_part_supported(const tsu_ising2d* L) {
 int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_t sweep0, uint32_t replica, int part) {
     tsu_ctx* ctx = L->ctx;
     const TileVariant& tv = kVariants[pick_variant(L)];
-    const int TILE_H = tv.H, TILE_WO = tv.WO, TILE_NO = tv.WO + 2;
+    const int TILE_H = tv.H, TILE_WO = tv.WO;
     if (!L->alloc[1]) {
         size_t bytes = (size_t)(L->rows + 2 * L->ghost) * L->pitch;
         TSU_HIP_TRY(ctx, hipMalloc(&L->alloc[1], bytes));
@@ -787,7 +903,7 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
     // (one workgroup per CU, or a small lattice: 8; large lattices with two workgroups per CU that overlap each other's
     // stage/store phases: 5)
     int kmax = L->sweeps_per_launch > 0 ? L->sweeps_per_launch
-                                        : ((tv.threads >= 1024 || (long long)L->rows * L->cols <= 4096ll * 4096ll) ? 8 : 5);
+                                        : ((tv.nib || tv.threads >= 1024 || (long long)L->rows * L->cols <= 4096ll * 4096ll) ? 8 : 5);
     if (kmax > KMAX) kmax = KMAX;
     const bool open_whole = !L->periodic && L->ghost == 0 && L->total_rows == L->rows;
     const bool slab = !L->wrap_rows && !open_whole;
@@ -858,19 +974,19 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
         if (res_th < TILE_H) res_th = TILE_H;
         const int extra = res_th * tiles_y - L->rows;
         res_ext = extra / 2;
-        const size_t lds_share = (tv.threads >= 1024 ? 160u : 80u) * 1024u;
-        const size_t lds_need = ((size_t)2 * (res_th + 4 * kmax) * TILE_NO + TILE_NO + 2 + 25) * sizeof(uint64_t);
+        const size_t lds_share = (tv.per_cu ? 160u / (unsigned)tv.per_cu : (tv.threads >= 1024 ? 160u : 80u)) * 1024u;
+        const size_t lds_need = tile_lds_bytes(tv, res_th + 4 * kmax);
         res_ok = (extra % 2 == 0) && res_ext <= L->ghost && lds_need <= lds_share;
     }
     if (res_ok) {
         // ---- tile-resident generations: every tile has its own workgroup on the chip for the whole call
         const int vi = (int)(&tv - kVariants);
-        const size_t lds_bytes = ((size_t)2 * (res_th + 4 * kmax) * TILE_NO + TILE_NO + 2 + 25) * sizeof(uint64_t);
+        const size_t lds_bytes = tile_lds_bytes(tv, res_th + 4 * kmax);
         TSU_HIP_TRY(ctx, tsu_func_allow_lds(ctx, (const void*)res_kern, 160 * 1024));
         int fit_per_cu = 0;
         // (occupancy for the standard tile height; a stretched slab tile was checked against the variant's LDS share)
         TSU_HIP_TRY(ctx, tsu_func_blocks_per_cu(ctx, (const void*)res_kern, tv.threads,
-                                                ((size_t)2 * (TILE_H + 4 * KMAX) * TILE_NO + TILE_NO + 2 + 25) * sizeof(uint64_t), &fit_per_cu));
+                                                tile_lds_bytes(tv, TILE_H + 4 * KMAX), &fit_per_cu));
         if ((long long)ntiles <= (long long)fit_per_cu * ctx->cus) {
             const size_t xstride = (size_t)4 * (2 * kmax * TILE_WO) + (size_t)4 * res_th;
             const size_t xneed = (size_t)2 * ntiles * xstride;
@@ -963,7 +1079,7 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
         p.src = L->alloc[L->cur] + (size_t)L->ghost * L->pitch;
         p.dst = L->alloc[L->cur ^ 1] + (size_t)L->ghost * L->pitch;
         int TR = TILE_H + 4 * k;
-        size_t lds_bytes = ((size_t)2 * TR * TILE_NO + TILE_NO + 2 + 25) * sizeof(uint64_t);
+        size_t lds_bytes = tile_lds_bytes(tv, TR);
         if (slab && part == TSU_PART_ALL) {
             const int ext = 2 * (n_sweeps - done - k);  // rows of ghost the remaining sweeps of this refresh period need
             p.r_begin = -ext;
@@ -973,13 +1089,13 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
             const int base_ty = (L->rows + TILE_H - 1) / TILE_H;
             int th = (p.r_end - p.r_begin + base_ty - 1) / base_ty;
             th += th & 1;
-            const size_t lds_share = (tv.threads >= 1024 ? 160u : 80u) * 1024u;
-            const size_t need = ((size_t)2 * (th + 4 * k) * TILE_NO + TILE_NO + 2 + 25) * sizeof(uint64_t);
+            const size_t lds_share = (tv.per_cu ? 160u / (unsigned)tv.per_cu : (tv.threads >= 1024 ? 160u : 80u)) * 1024u;
+            const size_t need = tile_lds_bytes(tv, th + 4 * k);
             if (need > lds_share || th < TILE_H) th = TILE_H;
             p.tile_h = th;
             tiles_y = (p.r_end - p.r_begin + th - 1) / th;
             TR = th + 4 * k;
-            lds_bytes = ((size_t)2 * TR * TILE_NO + TILE_NO + 2 + 25) * sizeof(uint64_t);
+            lds_bytes = tile_lds_bytes(tv, TR);
         }
         // tile rows 0 and tiles_y-1 read ghost rows (2k <= H); the others only read owned rows
         int n_ty = tiles_y;
