@@ -115,7 +115,7 @@ def test_grid_sample_replay(golden):
 @pytest.mark.parametrize("per", [0, 1])
 @pytest.mark.parametrize("mode", ["compat", "physical"])
 def test_config1_trajectory(golden, per, mode):
-    """IsingGrid 32x32, T=2.5, seed 42: states after 1/10/100 sweeps (C restatement, replayed MT19937)."""
+    """IsingGrid 32x32, T=2.5, seed 42: states after 1/10/100/1000 sweeps (C restatement, replayed MT19937)."""
     g = golden("g4_config1_trajectory")
     key = f"p{per}_{mode}"
     J = ora.ref_grid_coupling(32, 32, 1.0, bool(per))
@@ -126,7 +126,8 @@ def test_config1_trajectory(golden, per, mode):
     bits = np.random.randint(0, 2, size=1024)
     np.testing.assert_array_equal(bits.astype(np.int8), g[key + "_init"])
     done = 0
-    for cp, want, M, E in zip(g["checkpoints"][:3], g[key + "_states"][:3], g[key + "_M"], g[key + "_E"]):
+    assert list(g["checkpoints"]) == [1, 10, 100, 1000]
+    for cp, want, M, E in zip(g["checkpoints"], g[key + "_states"], g[key + "_M"], g[key + "_E"]):
         u = np.random.rand(int(cp) - done, 1024)
         bits = ora.c_dense_sweep_replay(bits, 4 * J, hb, 2.5, u)
         done = int(cp)
@@ -157,6 +158,22 @@ def test_langevin_step_and_chain(golden):
 
 
 # ----------------------------------------------------------------------------- G6 energies
+def test_grid_observables_of_a_samples_array(golden):
+    """magnetization / susceptibility / specific_heat of the reference on a fixed samples array (ising.py:183-233),
+    restated on the oracle's lattice builder: E(s) = -1/2 s'Js - h's, C = var(E) / (T^2 N), chi = var(M) N / T."""
+    g = golden("g6_observables")
+    J = ora.ref_grid_coupling(4, 6, 0.8, True)
+    h = np.ones(24) * 0.25
+    S = g["grid_samples"].astype(float)
+    E = np.array([-0.5 * s.dot(J).dot(s) - h.dot(s) for s in S])
+    np.testing.assert_allclose(E, g["grid_E"], rtol=0, atol=1e-12)
+    T, N = 1.9, 24
+    assert abs((np.mean(E ** 2) - np.mean(E) ** 2) / (T ** 2 * N) - float(g["grid_C"])) < 1e-12
+    M = S.sum(axis=1) / N
+    assert np.mean(S.sum(axis=1)) / N == float(g["grid_M"])
+    assert abs((np.mean(M ** 2) - np.mean(M) ** 2) * N / T - float(g["grid_chi"])) < 1e-12
+
+
 def test_dense_energy(golden):
     g = golden("g6_observables")
     for b, e, e0 in zip(g["dense_bits"], g["dense_E"], g["dense_E_nobias"]):
