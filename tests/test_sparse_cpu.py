@@ -17,8 +17,13 @@ from tsu.graph import canonical_csr, color_graph  # noqa: E402
 
 
 def random_graph(n, density, seed, self_loops=True):
+    """Symmetric sparse coupling matrix with about density * n^2 random entries per triangle (pairs drawn directly: scipy's
+    sp.random samples without replacement from n^2 slots, minutes at n = 60000) and a diagonal entry on 20 % of the sites."""
     rng = np.random.default_rng(seed)
-    M = sp.random(n, n, density=density, random_state=seed, format="csr", data_rvs=lambda k: rng.normal(size=k))
+    m = int(round(density * n * n))
+    i, j = rng.integers(0, n, size=m), rng.integers(0, n, size=m)
+    keep = i != j
+    M = sp.coo_matrix((rng.normal(size=int(keep.sum())), (i[keep], j[keep])), shape=(n, n)).tocsr()
     M = M + M.T
     if self_loops:
         d = np.where(rng.random(n) < 0.2, rng.normal(size=n), 0.0)

@@ -67,6 +67,9 @@ def color_graph(A: sp.csr_matrix, max_colors: int = 64) -> Tuple[np.ndarray, np.
     else:
         # --- general graph: repeated maximal-independent-set extraction
         rng = np.random.default_rng(12345)
+        deg = np.diff(P.indptr)
+        has_nb = deg > 0
+        starts = P.indptr[:-1][has_nb]            # np.maximum.reduceat over the rows that have neighbours
         left = np.ones(n, dtype=bool)
         c = 0
         while left.any():
@@ -78,7 +81,8 @@ def color_graph(A: sp.csr_matrix, max_colors: int = 64) -> Tuple[np.ndarray, np.
                 pr = np.where(cand, rng.random(n), -1.0)
                 # best priority among the candidate neighbours of every site
                 nb = np.full(n, -1.0)
-                np.maximum.at(nb, rows, pr[P.indices])
+                if starts.size:
+                    nb[has_nb] = np.maximum.reduceat(pr[P.indices], starts)
                 win = cand & (pr > nb)
                 chosen |= win
                 # winners and their neighbours leave the candidate set
