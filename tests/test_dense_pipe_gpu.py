@@ -1,0 +1,48 @@
+"""K2 pipeline kernel (k2_pipe: streamers + solver teams, csrc/dense_coop.hip) against the oracle, bit for bit, at sizes
+around its superblock sizes (4096 / 8192): one and several superblocks, partial last superblock, width not a multiple of the
+vector width's strip, f32 / f64 couplings, a bias, and long calls in which the fields are handed from sweep to sweep (a
+single-superblock system once raced here: its rows are committed by all solver workgroups just before the next solve)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as ora
+
+pytestmark = pytest.mark.gpu
+
+
+def _system(n, seed, f64=False, bias=True):
+    rng = np.random.default_rng(seed)
+    G = rng.standard_normal((n, n)).astype(np.float32)
+    J = ((G + G.T) / 2 / np.sqrt(n)).astype(np.float32)
+    np.fill_diagonal(J, 0.0)
+    b = rng.normal(size=n) * 0.1 if bias else None
+    return (J.astype(np.float64) if f64 else J), b, rng.integers(0, 2, size=n).astype(np.int8)
+
+
+@pytest.mark.parametrize("n,T,f64", [(1024, 1.0, False), (4096, 1.0, False), (4096, 1.0, True), (5000, 0.7, False), (6144, 1.0, False),
+                                     (8192, 1.0, False), (8196, 1.0, False), (9000, 1.3, True), (12288, 1.0, False), (12292, 0.4, False)])
+def test_pipeline_sweeps_match_oracle(n, T, f64):
+    from tsu import _hip
+    J, b, s0 = _system(n, n, f64)
+    d = _hip.DenseSystem(J, b, _hip.DTYPE_F64 if f64 else _hip.DTYPE_F32)
+    d.set_state(s0)
+    d.sweep(T, 3, seed=7, sweep0=2)
+    want = ora.dense_sweep_philox(s0, np.asarray(J, dtype=np.float64), b, T, 3, 7, sweep0=2)
+    np.testing.assert_array_equal(d.get_state(), want)
+    d.close()
+
+
+@pytest.mark.parametrize("n", [4096, 6144, 8192])
+def test_pipeline_long_call_hands_fields_from_sweep_to_sweep(n):
+    from tsu import _hip
+    J, _, s0 = _system(n, n + 1, bias=False)
+    d = _hip.DenseSystem(J, None, _hip.DTYPE_F32)
+    d.set_state(s0)
+    want, done = s0, 0
+    for k in (4, 20):
+        d.sweep(1.0, k, seed=1, sweep0=done)
+        want = ora.dense_sweep_philox(want, J.astype(np.float64), None, 1.0, k, 1, sweep0=done)
+        done += k
+        np.testing.assert_array_equal(d.get_state(), want)
+    assert abs(d.energy() - ora.c_dense_energy(want.astype(np.int64), J.astype(np.float64))) < 1e-6 * n
+    d.close()

@@ -40,6 +40,8 @@ struct tsu_dense {
     void* rep_buf;      // tsu_dense_sweep_replicas: states, replayed uniforms and per-replica parameters
     size_t rep_cap;
     int co_disabled;    // cooperative launch unavailable or failed once: use the multi-launch path
+    unsigned long long* pp_masks;  // k2_pipe: flip-mask granules of the solver teams
+    int pp_failed;      // k2_pipe ran and left the state half updated: the caller restores it, later calls skip the pipeline
 };
 
 

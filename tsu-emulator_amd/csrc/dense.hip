@@ -875,6 +875,7 @@ int tsu_dense_destroy(tsu_dense* d) {
     if (d->co_lists) (void)hipFree(d->co_lists);
     if (d->co_counts) (void)hipFree(d->co_counts);
     if (d->co_bar) (void)hipFree(d->co_bar);
+    if (d->pp_masks) (void)hipFree(d->pp_masks);
     delete d;
     return TSU_OK;
 }

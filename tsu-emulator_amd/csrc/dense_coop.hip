@@ -198,12 +198,12 @@ static __device__ __forceinline__ void stage_weights(const int8_t* w, int c0, in
 // c0, wbase and the row start are multiples of the vector width when VEC (checked by the host).  Eight 16-byte loads
 // per lane are issued before the first is consumed, also on short rows (out-of-range slots re-read the lane's first
 // vector with weight 0).
-template <typename TJ, bool VEC>
+template <typename TJ, bool VEC, int U = 8>
 static __device__ __noinline__ double wave_dot(const TJ* __restrict__ row, const int8_t* wl, int wbase, int c0, int c1,
                                                   int lane) {
     double acc = 0.0;
     if (VEC) {
-        constexpr int W = JVec<TJ>::W, U = 8;
+        constexpr int W = JVec<TJ>::W;
         const int c1v = c0 + (c1 - c0) / W * W;
         for (int j0 = c0 + lane * W; j0 < c1v; j0 += U * 64 * W) {
             typename JVec<TJ>::raw v[U];
@@ -386,6 +386,548 @@ __global__ __launch_bounds__(CO_THREADS) void k2_coop(CoopParams P) {
         for (int q = 0; q < 8; ++q) P.timeline[q] = tl[q];
 }
 
+
+// ==================================================================================================== k2_pipe
+// The same fixed point, organised as a two-role pipeline so that the latency-bound iterations of superblock s+1 hide
+// behind the bandwidth-bound strip of superblock s (profiles/r01_k2_notes.txt: ~40 grid-wide iterations per sweep at ~6 us
+// sat serially next to 0.2 ms of J strips):
+//   * STREAMERS (all workgroups but PP_NS): every wave owns a fixed set of rows (r = wave + m * waves) and keeps their
+//     fields for the whole call; per superblock it adds the strip J[r, sb] . flips to them -- the rows of the superblock
+//     that is solved NEXT first, published to P.f and signalled (C1), then all its other rows (C2).  This is the J stream:
+//     every element of J once per sweep.
+//   * SOLVERS (PP_NS workgroups): teams of PP_TW waves own 64 consecutive rows of the current superblock, lane = row.
+//     Jacobi iteration on FLIP MASKS: every team publishes the 64-bit mask of its rows' current decisions as two 8-byte
+//     {mask32, iteration tag} granules (one sc1 store each); every solver workgroup polls all 128 granules of the
+//     iteration (validated by their tags: no barrier, no atomics, two buffers by iteration parity), turns the TOGGLES
+//     against the previous iteration into a sorted list, and every row adds +-J^T[j][i] of the toggled earlier sites j
+//     (coalesced: lanes are consecutive i) to its correction and decides again.  Unchanged masks = the fixed point.
+//     One iteration is a publish -> poll hand-off (~1 us) plus one gather, instead of append atomics + a grid barrier.
+//   Hand-offs between the roles are two monotone counters (C1: fields of the next superblock complete; SOLVED: flips of
+//   the superblock final), everything shared goes through agent-scope (sc1) accesses drained before the signal.
+// Superblock size of the pipeline: the fixed costs (hand-offs, commit, the iterations' latency) are per superblock, the
+// exposed strip + triangle bytes and the iteration count grow with it.  Measured (fp32, T = 1, ms per sweep, 4096 / 8192):
+// n = 8192 0.203 / 0.180, 12288 0.296 / 0.285, 16384 0.381 / 0.398 -- 8192 up to n = 12288, 4096 above.
+#define PP_SB_MAX 8192
+#define PP_TEAMS 4                // 64-row groups per solver workgroup
+#define PP_GRAN_MAX (PP_SB_MAX / 32)
+#define PP_MAXR 24                // rows one streamer wave may own
+#define PB_C1 BAR_CNT(0)          // counter words on pages of their own (the grid-barrier layout is not used here)
+#define PB_SOLVED BAR_CNT(1)
+#define PB_T BAR_CNT(2)
+#define PP_BATCH 16               // J^T elements in flight per lane in the gather
+#ifndef PP_U
+#define PP_U 8                    // 16-byte loads in flight per lane in the streamers' strip passes
+#endif
+
+
+struct PipeParams {
+    const void* J;
+    const void* JT;
+    const double* bias;
+    int8_t* state;       // updated in place, superblock by superblock
+    double* f;           // fields of the superblock that is solved next (written by streamers, read by solvers)
+    int8_t* d1;          // flips of the superblock just solved, indexed from its first row
+    const double* uniforms;
+    unsigned long long* masks;  // [2][PP_GRAN] granules of the iteration + [PP_GRAN] first-guess granules (tag = superblock number)
+    double* corr;               // corrections of the first guesses (triangular pass, written by the streamers)
+    unsigned* bar;
+    int n, n_sweeps;
+    double T;
+    uint32_t sweep0, tag, k0, k1;
+    unsigned long long* timeline;  // TSU_K2_VERBOSE=2: solver workgroup 0, ticks in [wait C1, poll, gather+decide, commit], [4] iterations, [5] toggles;
+                                   // first streamer workgroup, wave 0: [6] wait SOLVED, [7] stage, [8] priority rows + signal, [9] other rows
+};
+
+// one lane polls, the workgroup follows its verdict
+static __device__ __forceinline__ bool wg_wait(unsigned* bar, int word, unsigned target, int* s_ok) {
+    if (threadIdx.x == 0) *s_ok = bar_wait(bar, &bar[word], target) ? 1 : 0;
+    __syncthreads();
+    const bool ok = *s_ok != 0;
+    __syncthreads();
+    return ok;
+}
+
+template <typename TJ, bool VEC, int SB>
+__global__ __launch_bounds__(CO_THREADS) void k2_pipe(PipeParams P) {
+    // superblock of SB positions: SB / 256 solver workgroups with four 64-row groups each, SB / 32 mask granules
+    constexpr int NS = SB / 256, GRAN = SB / 32, GPL = GRAN / 64;
+    static_assert(NS * PP_TEAMS * 64 == SB && (GPL == 2 || GPL == 4), "solver workgroups x 4 groups of 64 rows = one superblock");
+    extern __shared__ int8_t wl[];  // streamers: staged state (n bytes) / staged flips (SB bytes)
+    __shared__ double s_f[CO_THREADS / 64][PP_MAXR];
+    __shared__ double s_red[CO_THREADS / 64][PP_TEAMS][64];  // partial sums: [wave][group of the workgroup][row]
+    __shared__ int8_t s_sb[SB];          // solvers: state of the superblock at the start of the sweep
+    __shared__ unsigned s_m[2][GRAN];      // solvers: masks of the last two iterations
+    __shared__ unsigned short s_list[SB];
+    __shared__ int s_nlist, s_ok, s_fail;
+    __shared__ unsigned s_c1, s_t;
+    __shared__ int8_t wl2[SB];           // streamers: first guesses of the superblock that is solved next
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const TJ* __restrict__ J = (const TJ*)P.J;
+    const TJ* __restrict__ JT = (const TJ*)P.JT;
+    const int n = P.n, nsb = (n + SB - 1) / SB;
+    const double T = P.T, invT = 1.0 / P.T;
+    const unsigned n_stream = gridDim.x - NS;
+    if (threadIdx.x == 0) {
+        s_c1 = 0;
+        s_t = 0;
+        s_fail = 0;
+    }
+    __syncthreads();
+    unsigned ev = 0;    // C1 events so far (one per field pass and one per strip, the same count in both roles)
+    unsigned seq = 0;   // superblocks solved so far
+
+    if (blockIdx.x >= NS) {
+        // ------------------------------------------------------------------------------------------ streamer
+        // row r belongs to wave ws = r mod W.  Wave-major numbering: the W does not divide a superblock (4096 rows over 3840 waves),
+        // so 256 waves own TWO rows of every superblock -- numbered this way they are one wave in each workgroup rather than
+        // every wave of sixteen workgroups, and no CU has twice the others' priority work
+        const int W = (int)n_stream * (CO_THREADS / 64), ws = wv * (int)n_stream + (int)(blockIdx.x - NS);
+        unsigned tev = 0;  // triangular passes so far
+        auto signal_c1 = [&]() {  // this wave's stores are complete; the wave that completes the workgroup tells the solvers
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                const unsigned a = atomicAdd(&s_c1, 1u);
+                if (a + 1 == ev * (CO_THREADS / 64)) __hip_atomic_fetch_add(&P.bar[PB_C1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        };
+        // ---- T: the solvers answer the fields of superblock [q0, q1) with their first guesses (granules tagged with the
+        // superblock's number); the triangular pass over them -- the one heavy step of the fixed point, ~40 % of the sites
+        // flip -- is a stream and is done here, by the rows' owners: corr_i = sum_{q0 <= j < i} J_ij d0_j.  false = give up.
+        auto t_pass = [&](int q0, int q1, unsigned number) -> bool {
+            ++tev;
+            const unsigned long long* req = P.masks + 2 * GRAN;
+            if (wv == 0) {
+                unsigned long long gv[GPL];
+                const long long t0 = wall_clock64();
+                for (unsigned spins = 0;; ++spins) {
+                    bool okk = true;
+#pragma unroll
+                    for (int u = 0; u < GPL; ++u) {
+                        gv[u] = ld(req + GPL * lane + u);
+                        okk = okk && (unsigned)(gv[u] >> 32) == number;
+                    }
+                    if (__ballot(!okk) == 0ull) break;
+                    if ((spins & 63u) == 63u && (ld(&P.bar[BAR_ERR]) || wall_clock64() - t0 > CO_TIMEOUT)) {
+                        st(&P.bar[BAR_ERR], 1u);
+                        s_fail = 1;
+                        break;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < GPL; ++u) s_m[0][GPL * lane + u] = (unsigned)gv[u];
+            }
+            __syncthreads();
+            if (s_fail) return false;
+            for (int x = threadIdx.x * 4; x < SB; x += CO_THREADS * 4) {
+                const unsigned sv = q0 + x < q1 ? ld(reinterpret_cast<const unsigned*>(P.state + q0 + x)) : 0u;
+                const unsigned mb = s_m[0][x >> 5] >> (x & 31);
+                unsigned o = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int sj = (sv >> (8 * u)) & 1;
+                    const int dj = ((mb >> u) & 1u) ? (sj ? -1 : 1) : 0;
+                    o |= (unsigned)(dj & 0xFF) << (8 * u);
+                }
+                *reinterpret_cast<unsigned*>(wl2 + x) = o;
+            }
+            __syncthreads();
+            for (int r = ws; r < n; r += W) {
+                if (r < q0 || r >= q1) continue;
+                const double acc = wave_dot<TJ, VEC, PP_U>(J + (size_t)r * n, wl2, q0, q0, r, lane);
+                if (lane == 0) st(P.corr + r, acc);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                const unsigned a = atomicAdd(&s_t, 1u);
+                if (a + 1 == tev * (CO_THREADS / 64)) __hip_atomic_fetch_add(&P.bar[PB_T], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return true;
+        };
+        const bool stiming = P.timeline && blockIdx.x == NS && threadIdx.x == 0;
+        unsigned long long stl[4] = {0, 0, 0, 0};
+        long long stl_last = wall_clock64();
+#define ST_MARK(kind)                                       \
+    if (stiming) {                                          \
+        const long long now_ = wall_clock64();              \
+        stl[kind] += (unsigned long long)(now_ - stl_last); \
+        stl_last = now_;                                    \
+    }
+        for (int sw = 0; sw < P.n_sweeps; ++sw) {
+            const bool fresh = (sw % CO_REFRESH) == 0;
+            const bool next_incremental = sw + 1 < P.n_sweeps && ((sw + 1) % CO_REFRESH) != 0;
+            if (fresh) {
+                // fields from scratch (first sweep of a call and every CO_REFRESH sweeps): needs the complete state
+                if (!wg_wait(P.bar, PB_SOLVED, seq * NS, &s_ok)) return;
+                stage_weights(P.state, 0, n, wl);
+                __syncthreads();
+                ++ev;
+                int m = 0;
+                for (int r = ws; r < n; r += W, ++m) {
+                    const double acc = wave_dot<TJ, VEC>(J + (size_t)r * n, wl, 0, 0, n, lane);
+                    if (lane == 0) {
+                        const double F = acc + (P.bias ? P.bias[r] : 0.0);
+                        s_f[wv][m] = F;
+                        if (r < SB) st(P.f + r, F);
+                    }
+                }
+                signal_c1();
+                if (!t_pass(0, SB < n ? SB : n, seq + 1)) return;
+                __syncthreads();  // wl is restaged below
+            }
+            for (int sb = 0; sb < nsb; ++sb) {
+                const int p0 = sb * SB, pe = p0 + SB < n ? p0 + SB : n;
+                ++seq;
+                ST_MARK(3);
+                if (!wg_wait(P.bar, PB_SOLVED, seq * NS, &s_ok)) return;
+                ST_MARK(0);
+                stage_weights(P.d1, 0, pe - p0, wl);
+                __syncthreads();
+                ST_MARK(1);
+                ++ev;
+                // the superblock that is solved next: the following one, or the first of the next sweep when the fields
+                // are handed on; rows below row_lo are not needed again in this sweep and start afresh in the next
+                const bool last = sb == nsb - 1;
+                const int q0 = last ? 0 : pe, q1 = last ? (next_incremental ? (SB < n ? SB : n) : 0) : (pe + SB < n ? pe + SB : n);
+                const int row_lo = next_incremental ? 0 : pe;
+                int m = 0;
+                for (int r = ws; r < n; r += W, ++m) {
+                    if (r < q0 || r >= q1) continue;
+                    const double acc = wave_dot<TJ, VEC, PP_U>(J + (size_t)r * n, wl, p0, p0, pe, lane);
+                    if (lane == 0) {
+                        const double F = s_f[wv][m] + acc;
+                        s_f[wv][m] = F;
+                        st(P.f + r, F);
+                    }
+                }
+                signal_c1();
+                // nothing else is started until EVERY workgroup's priority rows are through: other loads would queue in
+                // front of the stragglers' (a few waves own two priority rows), and the solvers' start is the critical path
+                if (q1 > q0) {
+                    if (!wg_wait(P.bar, PB_C1, ev * n_stream, &s_ok)) return;
+                    if (!t_pass(q0, q1, seq + 1)) return;
+                }
+                ST_MARK(2);
+                m = 0;
+                for (int r = ws; r < n; r += W, ++m) {
+                    if (r < row_lo || (r >= q0 && r < q1)) continue;
+                    const double acc = wave_dot<TJ, VEC, PP_U>(J + (size_t)r * n, wl, p0, p0, pe, lane);
+                    if (lane == 0) s_f[wv][m] += acc;
+                }
+                __syncthreads();  // every wave is done with wl before it is restaged
+            }
+        }
+        if (stiming)
+            for (int x = 0; x < 4; ++x) P.timeline[6 + x] = stl[x];
+#undef ST_MARK
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------------------- solver
+    // Workgroup b owns the four 64-row groups {b, 31-b, 32+b, 63-b} of the superblock: the work of a group grows with its
+    // index (a row reads the toggles of all EARLIER sites), and these quadruples carry the same total.  Waves 0..3 are the
+    // groups' row owners (lane = row: field, logit, correction, decision); all 16 waves share the gather of the
+    // workgroup's four groups (list entries c = wave mod 16) and hand their partial sums over through LDS.
+    const int b = (int)blockIdx.x;
+    const int grp[PP_TEAMS] = {b, 2 * NS - 1 - b, 2 * NS + b, 4 * NS - 1 - b};
+    const bool owner = wv < PP_TEAMS;
+    const int g = grp[wv & (PP_TEAMS - 1)];            // (owners) my group
+    unsigned itag = 1;                                 // tag of the next iteration's granules (0 = never written)
+    unsigned tev = 0;                                  // triangular passes so far
+    const bool timing = P.timeline && blockIdx.x == 0 && threadIdx.x == 0;
+    unsigned long long tl[6] = {0, 0, 0, 0, 0, 0};
+    long long tl_last = wall_clock64();
+#define PP_MARK(kind)                                      \
+    if (timing) {                                          \
+        const long long now_ = wall_clock64();             \
+        tl[kind] += (unsigned long long)(now_ - tl_last);  \
+        tl_last = now_;                                    \
+    }
+    for (int sw = 0; sw < P.n_sweeps; ++sw) {
+        const uint32_t t = P.sweep0 + (uint32_t)sw;
+        const double* uni = P.uniforms ? P.uniforms + (size_t)sw * n : nullptr;
+        if ((sw % CO_REFRESH) == 0) ++ev;
+        for (int sb = 0; sb < nsb; ++sb) {
+            const int p0 = sb * SB, pe = p0 + SB < n ? p0 + SB : n, cnt = pe - p0;
+            const int il = 64 * g + lane, i = p0 + il;
+            const bool active = owner && il < cnt;
+            // my logit: before the fields arrive
+            const double lg = active ? co_logit((uint32_t)i, uni, t, P.tag, P.k0, P.k1) : 0.0;
+            PP_MARK(3);
+            if (!wg_wait(P.bar, PB_C1, ev * n_stream, &s_ok)) return;
+            PP_MARK(0);
+            // state of the superblock at the start of the sweep.  Read AFTER the fields have arrived: with a single superblock
+            // its rows were committed by the other solver workgroups just before (the previous sweep's solve), and only the
+            // strip that followed -- which waited for all of them -- orders those stores before this read.
+            for (int x = threadIdx.x; x < SB; x += CO_THREADS) s_sb[x] = x < cnt ? ld(P.state + p0 + x) : (int8_t)0;
+            __syncthreads();
+            const double fi = active ? ld(P.f + i) : 0.0;
+            const int si = s_sb[il];
+            double corr = 0.0;
+            bool flipped = active && co_decide(fi, lg, T, invT, (uint32_t)i, uni, t, P.tag, P.k0, P.k1) != si;
+            int k = 0;
+            while (true) {
+                // publish iteration k, then collect every group's iteration-k masks
+                unsigned long long* slot = P.masks + (size_t)(k & 1) * GRAN;
+                if (owner) {
+                    const unsigned long long mk = __ballot(flipped);
+                    if (lane < 2) st(slot + 2 * g + lane, (unsigned long long)(uint32_t)(mk >> (32 * lane)) | ((unsigned long long)(itag + (unsigned)k) << 32));
+                    // the first guesses also go to the streamers (tag = number of this superblock), who return their triangular pass
+                    if (k == 0 && lane < 2)
+                        st(P.masks + 2 * GRAN + 2 * g + lane, (unsigned long long)(uint32_t)(mk >> (32 * lane)) | ((unsigned long long)(seq + 1) << 32));
+                }
+                if (wv == PP_TEAMS) {
+                    // (a wave that owns no rows) lane l collects GPL consecutive granules = the 32 GPL sites from
+                    // 32 GPL l on; every granule validates itself by its tag
+                    unsigned long long gv[GPL];
+                    const long long t0 = wall_clock64();
+                    for (unsigned spins = 0;; ++spins) {
+                        bool okk = true;
+#pragma unroll
+                        for (int u = 0; u < GPL; ++u) {
+                            gv[u] = ld(slot + GPL * lane + u);
+                            okk = okk && (unsigned)(gv[u] >> 32) == itag + (unsigned)k;
+                        }
+                        if (__ballot(!okk) == 0ull) break;
+                        if ((spins & 63u) == 63u) {
+                            if (ld(&P.bar[BAR_ERR]) || wall_clock64() - t0 > CO_TIMEOUT) {
+                                st(&P.bar[BAR_ERR], 1u);
+                                s_fail = 1;
+                                break;
+                            }
+                        }
+                    }
+                    // sorted list of the toggled sites: j | (contribution negative << 15); lane l writes its sites' entries
+                    unsigned cur[GPL], tog[GPL];
+                    int pc = 0;
+#pragma unroll
+                    for (int u = 0; u < GPL; ++u) {
+                        cur[u] = (unsigned)gv[u];
+                        const unsigned old = k ? s_m[(k - 1) & 1][GPL * lane + u] : 0u;
+                        s_m[k & 1][GPL * lane + u] = cur[u];
+                        tog[u] = cur[u] ^ old;
+                        pc += __popc(tog[u]);
+                    }
+                    int off = pc;
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const int v = __shfl_up(off, d, 64);
+                        if (lane >= d) off += v;
+                    }
+                    if (lane == 63) s_nlist = off;
+                    off -= pc;
+#pragma unroll
+                    for (int u = 0; u < GPL; ++u) {
+                        unsigned tt = tog[u];
+                        while (tt) {
+                            const int bpos = __ffs((int)tt) - 1;
+                            tt &= tt - 1;
+                            const int j = 32 * (GPL * lane + u) + bpos;
+                            const bool on = (cur[u] >> bpos) & 1u;           // the site is flipped now: + d_j, else - d_j
+                            const bool neg = (s_sb[j] != 0) == on;           // d_j = -1 for a site that was 1
+                            s_list[off++] = (unsigned short)(j | (neg ? 0x8000 : 0));
+                        }
+                    }
+                }
+                __syncthreads();
+                if (s_fail) return;
+                const int nl = s_nlist;
+                PP_MARK(1);
+                if (timing) {
+                    tl[4] += 1;
+                    tl[5] += (unsigned long long)nl;
+                }
+                if (k > 0 && nl == 0) break;  // nothing toggled anywhere: the fixed point
+                if (k == 0) {
+                    // iteration 0 -> 1: all first guesses at once = the streamers' triangular pass
+                    ++tev;
+                    if (!wg_wait(P.bar, PB_T, tev * n_stream, &s_ok)) return;
+                    if (owner) {
+                        corr = active ? ld(P.corr + i) : 0.0;
+                        flipped = active && co_decide(fi + corr, lg, T, invT, (uint32_t)i, uni, t, P.tag, P.k0, P.k1) != si;
+                    }
+                    ++k;
+                    PP_MARK(2);
+                    continue;
+                }
+                // the toggles of earlier sites for the workgroup's four groups: PP_BATCH / 4 list entries x 4 groups per round,
+                // all loads of a round in flight together (the lists are short after the first guesses: one round trip per
+                // iteration).  The list ascends: a wave stops where its entries pass the end of the last group.
+                {
+                    constexpr int EB = PP_BATCH / PP_TEAMS, NWV = CO_THREADS / 64;
+                    double acc[PP_TEAMS] = {0.0, 0.0, 0.0, 0.0};
+                    const int j_last = 64 * (grp[PP_TEAMS - 1] + 1);
+                    for (int c0 = wv; c0 < nl; c0 += NWV * EB) {
+                        if ((int)(s_list[c0] & 0x7FFF) >= j_last) break;
+                        TJ x[PP_TEAMS][EB];
+                        int e[EB];
+#pragma unroll
+                        for (int u = 0; u < EB; ++u) {
+                            const int c = c0 + u * NWV;
+                            e[u] = c < nl ? (int)s_list[c] : 0x7FFF;
+                            const int j = e[u] & 0x7FFF;
+#pragma unroll
+                            for (int gi = 0; gi < PP_TEAMS; ++gi) {
+                                // unconditional loads (a predicated one becomes a branch and the loads serial round trips):
+                                // entries beyond the group's end read row 0 and are weighted 0 below (j >= j_end > gl)
+                                const int gl = 64 * grp[gi] + lane;
+                                x[gi][u] = JT[(size_t)(p0 + (j < 64 * (grp[gi] + 1) ? j : 0)) * n + (size_t)(p0 + (gl < cnt ? gl : 0))];
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < EB; ++u) {
+                            const int j = e[u] & 0x7FFF;
+#pragma unroll
+                            for (int gi = 0; gi < PP_TEAMS; ++gi) {
+                                const double v = (j < 64 * grp[gi] + lane) ? (double)x[gi][u] : 0.0;  // only earlier sites
+                                acc[gi] += (e[u] & 0x8000) ? -v : v;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int gi = 0; gi < PP_TEAMS; ++gi) s_red[wv][gi][lane] = acc[gi];
+                }
+                __syncthreads();
+                if (owner) {
+                    double tot = 0.0;
+#pragma unroll
+                    for (int u = 0; u < CO_THREADS / 64; ++u) tot += s_red[u][wv][lane];
+                    corr += tot;
+                    flipped = active && co_decide(fi + corr, lg, T, invT, (uint32_t)i, uni, t, P.tag, P.k0, P.k1) != si;
+                }
+                ++k;
+                if (k > SB + 2) {  // cannot happen (the iteration is exact after SB rounds): report, leave
+                    if (threadIdx.x == 0) st(&P.bar[BAR_ERR + 2], 1u);
+                    break;
+                }
+                __syncthreads();  // s_red and s_list are rewritten in the next round
+                PP_MARK(2);
+            }
+            itag += (unsigned)k + 2u;
+            // commit: flips for the streamers' strip, the new state in place (four rows per dword store)
+            const int dn = flipped ? (si ? -1 : 1) : 0;
+            const int b0 = dn & 0xFF, c0s = (si + dn) & 0xFF;
+            unsigned pd = (unsigned)b0, ps = (unsigned)c0s;
+            pd |= (unsigned)__shfl_down(b0, 1, 64) << 8 | (unsigned)__shfl_down(b0, 2, 64) << 16 | (unsigned)__shfl_down(b0, 3, 64) << 24;
+            ps |= (unsigned)__shfl_down(c0s, 1, 64) << 8 | (unsigned)__shfl_down(c0s, 2, 64) << 16 | (unsigned)__shfl_down(c0s, 3, 64) << 24;
+            if (owner && (lane & 3) == 0 && il < cnt) {  // cnt is a multiple of 4 (n is)
+                st(reinterpret_cast<unsigned*>(P.d1 + il), pd);
+                st(reinterpret_cast<unsigned*>(P.state + i), ps);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            ++seq;
+            ++ev;
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(&P.bar[PB_SOLVED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (timing)
+        for (int x = 0; x < 6; ++x) P.timeline[x] = tl[x];
+#undef PP_MARK
+}
+
+template <typename TJ>
+static int pipe_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint32_t sweep0, uint32_t replica, bool have_uni,
+                      int* done) {
+    tsu_ctx* ctx = d->ctx;
+    const int n = d->n;
+    *done = 0;
+    static int use_pipe = -1;
+    if (use_pipe < 0) {
+        const char* e = getenv("TSU_K2_PIPE");
+        use_pipe = e ? atoi(e) : 1;
+    }
+    const int grid = ctx->cus;
+    static int sb_env = -1;
+    if (sb_env < 0) {
+        const char* e = getenv("TSU_K2_PIPE_SB");
+        sb_env = e ? atoi(e) : 0;
+    }
+    const int sb = (sb_env == 4096 || sb_env == 8192) ? sb_env : (n <= 12288 ? 8192 : 4096);
+    const int ns = sb / 256;
+    if (!use_pipe || n > CO_MAX_N || n < 1024 || grid < 2 * ns) return TSU_OK;
+    if ((long long)(grid - ns) * (CO_THREADS / 64) * PP_MAXR < n) return TSU_OK;
+    if (n % 4) return TSU_OK;  // state / flips travel as dwords
+    const bool vec = (n % JVec<TJ>::W) == 0;
+    void (*kern)(PipeParams) = sb == 8192 ? (vec ? k2_pipe<TJ, true, 8192> : k2_pipe<TJ, false, 8192>) : (vec ? k2_pipe<TJ, true, 4096> : k2_pipe<TJ, false, 4096>);
+    const size_t lds_bytes = (size_t)((n > sb ? n : sb) + 15) / 16 * 16;
+    if (tsu_func_allow_lds(ctx, (const void*)kern, (int)lds_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return TSU_OK;
+    }
+    int per_cu = 0;
+    if (tsu_func_blocks_per_cu(ctx, (const void*)kern, CO_THREADS, lds_bytes, &per_cu) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        return TSU_OK;
+    }
+    if (!d->co_bar) TSU_HIP_TRY(ctx, hipMalloc(&d->co_bar, BAR_WORDS * sizeof(unsigned)));
+    if (!d->co_d1) TSU_HIP_TRY(ctx, hipMalloc(&d->co_d1, (size_t)n));
+    if (!d->pp_masks) TSU_HIP_TRY(ctx, hipMalloc(&d->pp_masks, 3 * PP_GRAN_MAX * sizeof(unsigned long long)));
+    if (!d->co_corr) TSU_HIP_TRY(ctx, hipMalloc(&d->co_corr, (size_t)n * 8));
+    TSU_HIP_TRY(ctx, hipMemsetAsync(d->co_bar, 0, BAR_WORDS * sizeof(unsigned), ctx->stream));
+    TSU_HIP_TRY(ctx, hipMemsetAsync(d->pp_masks, 0, 3 * PP_GRAN_MAX * sizeof(unsigned long long), ctx->stream));
+    PipeParams P;
+    P.J = d->J;
+    P.JT = d->JT;
+    P.bias = d->bias;
+    P.state = d->state;
+    P.f = d->field;
+    P.d1 = d->co_d1;
+    P.uniforms = have_uni ? d->uniforms : nullptr;
+    P.masks = d->pp_masks;
+    P.corr = d->co_corr;
+    P.bar = d->co_bar;
+    P.n = n;
+    P.n_sweeps = n_sweeps;
+    P.T = T;
+    P.sweep0 = sweep0;
+    P.tag = TSU_TAG_DENSE | (replica << 8);
+    P.k0 = (uint32_t)seed;
+    P.k1 = (uint32_t)(seed >> 32);
+    const char* verbose = getenv("TSU_K2_VERBOSE");
+    unsigned long long* d_tl = nullptr;
+    if (verbose && atoi(verbose) >= 2) {
+        TSU_HIP_TRY(ctx, hipMalloc(&d_tl, 10 * sizeof(unsigned long long)));
+        TSU_HIP_TRY(ctx, hipMemsetAsync(d_tl, 0, 10 * sizeof(unsigned long long), ctx->stream));
+    }
+    P.timeline = d_tl;
+    {
+        const int rcx = tsu_grid_exclusive_begin(ctx);
+        if (rcx != TSU_OK) return rcx;
+    }
+    hipError_t e = tsu_launch_grid_sync(ctx, (const void*)kern, dim3((unsigned)grid), dim3(CO_THREADS), &P, lds_bytes, ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (d_tl) (void)hipFree(d_tl);
+        return TSU_OK;
+    }
+    {
+        const int rcx = tsu_grid_exclusive_end(ctx);
+        if (rcx != TSU_OK) return rcx;
+    }
+    unsigned h[4];
+    TSU_HIP_TRY(ctx, hipMemcpyAsync(h + 1, d->co_bar + BAR_ERR, 3 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (d_tl) {
+        unsigned long long tl[10];
+        (void)hipMemcpy(tl, d_tl, sizeof(tl), hipMemcpyDeviceToHost);
+        (void)hipFree(d_tl);
+        const double nsb_tot = (double)n_sweeps * ((n + sb - 1) / sb);
+        fprintf(stderr, "[tsu] k2_pipe n=%d (superblocks of %d), %d sweeps; per superblock: wait C1 %.1f us, poll %.1f us, gather+decide %.1f us, commit+prologue %.1f us, "
+                        "%.1f iterations, %.0f toggles\n", n, sb, n_sweeps, tl[0] / 100.0 / nsb_tot, tl[1] / 100.0 / nsb_tot, tl[2] / 100.0 / nsb_tot,
+                tl[3] / 100.0 / nsb_tot, tl[4] / nsb_tot, tl[5] / nsb_tot);
+        fprintf(stderr, "[tsu]   streamer wave: wait SOLVED %.1f us, stage flips %.1f us, priority rows + signal %.1f us, other rows %.1f us\n",
+                tl[6] / 100.0 / nsb_tot, tl[7] / 100.0 / nsb_tot, tl[8] / 100.0 / nsb_tot, tl[9] / 100.0 / nsb_tot);
+    }
+    if (h[1] || h[3]) {
+        // a wait expired (GPU shared with another long-running kernel) or -- never seen -- no fixed point: the caller
+        // restores the state from its backup and the other paths take the call
+        fprintf(stderr, "[tsu] dense sweep (pipeline): %s; continuing on the barrier path\n", h[1] ? "a wait timed out (GPU shared?)" : "no fixed point");
+        d->pp_failed = 1;
+        return TSU_OK;
+    }
+    *done = 1;
+    return TSU_OK;
+}
+
 template <typename TJ>
 static int coop_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint32_t sweep0, uint32_t replica, bool have_uni,
                       int* done) {
@@ -408,14 +950,13 @@ static int coop_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint3
     }
     const int nsb = (n + SB_SIZE - 1) / SB_SIZE;
     const size_t count_ints = (size_t)n_sweeps * nsb * CO_SLOTS;
-    if (!d->co_logit) {
-        TSU_HIP_TRY(ctx, hipMalloc(&d->co_logit, (size_t)n * 8));
-        TSU_HIP_TRY(ctx, hipMalloc(&d->co_corr, (size_t)n * 8));
-        TSU_HIP_TRY(ctx, hipMalloc(&d->co_d0, (size_t)n));
-        TSU_HIP_TRY(ctx, hipMalloc(&d->co_d1, (size_t)n));
-        TSU_HIP_TRY(ctx, hipMalloc(&d->co_lists, 2 * SB_SIZE * sizeof(int)));
-        TSU_HIP_TRY(ctx, hipMalloc(&d->co_bar, BAR_WORDS * sizeof(unsigned)));
-    }
+    // (the pipeline kernel may have created some of these already)
+    if (!d->co_logit) TSU_HIP_TRY(ctx, hipMalloc(&d->co_logit, (size_t)n * 8));
+    if (!d->co_corr) TSU_HIP_TRY(ctx, hipMalloc(&d->co_corr, (size_t)n * 8));
+    if (!d->co_d0) TSU_HIP_TRY(ctx, hipMalloc(&d->co_d0, (size_t)n));
+    if (!d->co_d1) TSU_HIP_TRY(ctx, hipMalloc(&d->co_d1, (size_t)n));
+    if (!d->co_lists) TSU_HIP_TRY(ctx, hipMalloc(&d->co_lists, 2 * SB_SIZE * sizeof(int)));
+    if (!d->co_bar) TSU_HIP_TRY(ctx, hipMalloc(&d->co_bar, BAR_WORDS * sizeof(unsigned)));
     if (d->co_counts_cap < count_ints) {
         if (d->co_counts) (void)hipFree(d->co_counts);
         d->co_counts = nullptr;
@@ -506,6 +1047,15 @@ static int coop_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint3
 
 int tsu_dense_coop_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint32_t sweep0, uint32_t replica, bool have_uni,
                          int* done) {
+    // first choice: the two-role pipeline (in place on d->state); it declines small / odd systems and reports a failed
+    // run with *done = 0, in which case the caller has restored the state and the barrier kernel below takes the call
+    if (!d->pp_failed) {
+        const int rc = d->dtype == TSU_DTYPE_F64 ? pipe_sweep<double>(d, T, n_sweeps, seed, sweep0, replica, have_uni, done)
+                                                 : pipe_sweep<float>(d, T, n_sweeps, seed, sweep0, replica, have_uni, done);
+        if (rc != TSU_OK || *done) return rc;
+        if (d->pp_failed)  // it ran and gave up half way: back to the state at the start of the call (the caller's backup)
+            TSU_HIP_TRY(d->ctx, hipMemcpyAsync(d->state, d->backup, (size_t)d->n, hipMemcpyDeviceToDevice, d->ctx->stream));
+    }
     if (d->dtype == TSU_DTYPE_F64) return coop_sweep<double>(d, T, n_sweeps, seed, sweep0, replica, have_uni, done);
     return coop_sweep<float>(d, T, n_sweeps, seed, sweep0, replica, have_uni, done);
 }

@@ -12,7 +12,7 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libtsu_hip.so")
+LIB_PATH = os.environ.get("TSU_HIP_LIB") or os.path.join(_HERE, "_lib", "libtsu_hip.so")  # (TSU_HIP_LIB: development builds)
 
 TSU_OK = 0
 TSU_E_INVALID, TSU_E_NOMEM, TSU_E_HIP, TSU_E_RCCL, TSU_E_UNSUPPORTED = -1, -2, -3, -4, -5
