@@ -447,7 +447,7 @@ static __device__ __forceinline__ bool wg_wait(unsigned* bar, int word, unsigned
     return ok;
 }
 
-template <typename TJ, bool VEC, int SB>
+template <typename TJ, bool VEC, int SB, int U2>
 __global__ __launch_bounds__(CO_THREADS) void k2_pipe(PipeParams P) {
     // superblock of SB positions: SB / 256 solver workgroups with four 64-row groups each, SB / 32 mask granules
     constexpr int NS = SB / 256, GRAN = SB / 32, GPL = GRAN / 64;
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(CO_THREADS) void k2_pipe(PipeParams P) {
                 m = 0;
                 for (int r = ws; r < n; r += W, ++m) {
                     if (r < row_lo || (r >= q0 && r < q1)) continue;
-                    const double acc = wave_dot<TJ, VEC, PP_U>(J + (size_t)r * n, wl, p0, p0, pe, lane);
+                    const double acc = wave_dot<TJ, VEC, U2>(J + (size_t)r * n, wl, p0, p0, pe, lane);
                     if (lane == 0) s_f[wv][m] += acc;
                 }
                 __syncthreads();  // every wave is done with wl before it is restaged
@@ -847,7 +847,13 @@ static int pipe_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint3
     if ((long long)(grid - ns) * (CO_THREADS / 64) * PP_MAXR < n) return TSU_OK;
     if (n % 4) return TSU_OK;  // state / flips travel as dwords
     const bool vec = (n % JVec<TJ>::W) == 0;
-    void (*kern)(PipeParams) = sb == 8192 ? (vec ? k2_pipe<TJ, true, 8192> : k2_pipe<TJ, false, 8192>) : (vec ? k2_pipe<TJ, true, 4096> : k2_pipe<TJ, false, 4096>);
+    // loads in flight per lane on the rows that are not urgent (they run beside the solvers' latency-bound iterations, whose
+    // hand-offs and gathers queue behind them): ONE while those rows take less time than the iterations anyway (N = 16384:
+    // 0.386 -> 0.353 ms per sweep; profiles/r02_k2_notes.txt), eight once the strips dominate
+    const bool gentle = n <= 20480;
+    void (*kern)(PipeParams) = sb == 8192 ? (vec ? k2_pipe<TJ, true, 8192, 1> : k2_pipe<TJ, false, 8192, 1>)
+                               : gentle   ? (vec ? k2_pipe<TJ, true, 4096, 1> : k2_pipe<TJ, false, 4096, 1>)
+                                          : (vec ? k2_pipe<TJ, true, 4096, 8> : k2_pipe<TJ, false, 4096, 8>);
     const size_t lds_bytes = (size_t)((n > sb ? n : sb) + 15) / 16 * 16;
     if (tsu_func_allow_lds(ctx, (const void*)kern, (int)lds_bytes) != hipSuccess) {
         (void)hipGetLastError();
