@@ -430,6 +430,7 @@ struct PipeParams {
     const double* uniforms;
     unsigned long long* masks;  // [2][PP_GRAN] granules of the iteration + [PP_GRAN] first-guess granules (tag = superblock number)
     double* corr;               // corrections of the first guesses (triangular pass, written by the streamers)
+    int8_t* d0;                 // first guesses of the superblock that is solved next, from its first row (written by the rows' owners)
     unsigned* bar;
     int n, n_sweeps;
     double T;
@@ -483,6 +484,14 @@ __global__ __launch_bounds__(CO_THREADS) void k2_pipe(PipeParams P) {
         // every wave of sixteen workgroups, and no CU has twice the others' priority work
         const int W = (int)n_stream * (CO_THREADS / 64), ws = wv * (int)n_stream + (int)(blockIdx.x - NS);
         unsigned tev = 0;  // triangular passes so far
+        // first guess of row r (of the superblock that starts at q0, solved in sweep number sw_of): the decision on the field alone
+        auto first_guess = [&](int r, int q0, double F, int sw_of) {
+            const uint32_t tt = P.sweep0 + (uint32_t)sw_of;
+            const double* un = P.uniforms ? P.uniforms + (size_t)sw_of * n : nullptr;
+            const double lgr = co_logit((uint32_t)r, un, tt, P.tag, P.k0, P.k1);
+            const int sr = ld(P.state + r);
+            st(P.d0 + (r - q0), (int8_t)(co_decide(F, lgr, T, invT, (uint32_t)r, un, tt, P.tag, P.k0, P.k1) - sr));
+        };
         auto signal_c1 = [&]() {  // this wave's stores are complete; the wave that completes the workgroup tells the solvers
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) {
@@ -490,46 +499,13 @@ __global__ __launch_bounds__(CO_THREADS) void k2_pipe(PipeParams P) {
                 if (a + 1 == ev * (CO_THREADS / 64)) __hip_atomic_fetch_add(&P.bar[PB_C1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         };
-        // ---- T: the solvers answer the fields of superblock [q0, q1) with their first guesses (granules tagged with the
-        // superblock's number); the triangular pass over them -- the one heavy step of the fixed point, ~40 % of the sites
-        // flip -- is a stream and is done here, by the rows' owners: corr_i = sum_{q0 <= j < i} J_ij d0_j.  false = give up.
-        auto t_pass = [&](int q0, int q1, unsigned number) -> bool {
+        // ---- T: once EVERY row of superblock [q0, q1) has its field, its first guesses d0_i = decide(f_i) - s_i are known --
+        // each row's owner computes its own with the field (the solvers compute the very same decisions for their masks) --
+        // and the triangular pass over them -- the one heavy step of the fixed point, ~40 % of the sites flip -- is a
+        // stream and is done here, by the rows' owners: corr_i = sum_{q0 <= j < i} J_ij d0_j.
+        auto t_pass = [&](int q0, int q1) -> bool {
             ++tev;
-            const unsigned long long* req = P.masks + 2 * GRAN;
-            if (wv == 0) {
-                unsigned long long gv[GPL];
-                const long long t0 = wall_clock64();
-                for (unsigned spins = 0;; ++spins) {
-                    bool okk = true;
-#pragma unroll
-                    for (int u = 0; u < GPL; ++u) {
-                        gv[u] = ld(req + GPL * lane + u);
-                        okk = okk && (unsigned)(gv[u] >> 32) == number;
-                    }
-                    if (__ballot(!okk) == 0ull) break;
-                    if ((spins & 63u) == 63u && (ld(&P.bar[BAR_ERR]) || wall_clock64() - t0 > CO_TIMEOUT)) {
-                        st(&P.bar[BAR_ERR], 1u);
-                        s_fail = 1;
-                        break;
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < GPL; ++u) s_m[0][GPL * lane + u] = (unsigned)gv[u];
-            }
-            __syncthreads();
-            if (s_fail) return false;
-            for (int x = threadIdx.x * 4; x < SB; x += CO_THREADS * 4) {
-                const unsigned sv = q0 + x < q1 ? ld(reinterpret_cast<const unsigned*>(P.state + q0 + x)) : 0u;
-                const unsigned mb = s_m[0][x >> 5] >> (x & 31);
-                unsigned o = 0;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int sj = (sv >> (8 * u)) & 1;
-                    const int dj = ((mb >> u) & 1u) ? (sj ? -1 : 1) : 0;
-                    o |= (unsigned)(dj & 0xFF) << (8 * u);
-                }
-                *reinterpret_cast<unsigned*>(wl2 + x) = o;
-            }
+            stage_weights(P.d0, 0, q1 - q0, wl2);
             __syncthreads();
             for (int r = ws; r < n; r += W) {
                 if (r < q0 || r >= q1) continue;
@@ -567,11 +543,15 @@ __global__ __launch_bounds__(CO_THREADS) void k2_pipe(PipeParams P) {
                     if (lane == 0) {
                         const double F = acc + (P.bias ? P.bias[r] : 0.0);
                         s_f[wv][m] = F;
-                        if (r < SB) st(P.f + r, F);
+                        if (r < SB) {
+                            st(P.f + r, F);
+                            first_guess(r, 0, F, sw);
+                        }
                     }
                 }
                 signal_c1();
-                if (!t_pass(0, SB < n ? SB : n, seq + 1)) return;
+                if (!wg_wait(P.bar, PB_C1, ev * n_stream, &s_ok)) return;
+                if (!t_pass(0, SB < n ? SB : n)) return;
                 __syncthreads();  // wl is restaged below
             }
             for (int sb = 0; sb < nsb; ++sb) {
@@ -597,6 +577,7 @@ __global__ __launch_bounds__(CO_THREADS) void k2_pipe(PipeParams P) {
                         const double F = s_f[wv][m] + acc;
                         s_f[wv][m] = F;
                         st(P.f + r, F);
+                        first_guess(r, q0, F, last ? sw + 1 : sw);
                     }
                 }
                 signal_c1();
@@ -604,7 +585,7 @@ __global__ __launch_bounds__(CO_THREADS) void k2_pipe(PipeParams P) {
                 // front of the stragglers' (a few waves own two priority rows), and the solvers' start is the critical path
                 if (q1 > q0) {
                     if (!wg_wait(P.bar, PB_C1, ev * n_stream, &s_ok)) return;
-                    if (!t_pass(q0, q1, seq + 1)) return;
+                    if (!t_pass(q0, q1)) return;
                 }
                 ST_MARK(2);
                 m = 0;
@@ -671,9 +652,6 @@ __global__ __launch_bounds__(CO_THREADS) void k2_pipe(PipeParams P) {
                 if (owner) {
                     const unsigned long long mk = __ballot(flipped);
                     if (lane < 2) st(slot + 2 * g + lane, (unsigned long long)(uint32_t)(mk >> (32 * lane)) | ((unsigned long long)(itag + (unsigned)k) << 32));
-                    // the first guesses also go to the streamers (tag = number of this superblock), who return their triangular pass
-                    if (k == 0 && lane < 2)
-                        st(P.masks + 2 * GRAN + 2 * g + lane, (unsigned long long)(uint32_t)(mk >> (32 * lane)) | ((unsigned long long)(seq + 1) << 32));
                 }
                 if (wv == PP_TEAMS) {
                     // (a wave that owns no rows) lane l collects GPL consecutive granules = the 32 GPL sites from
@@ -868,6 +846,7 @@ static int pipe_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint3
     if (!d->co_d1) TSU_HIP_TRY(ctx, hipMalloc(&d->co_d1, (size_t)n));
     if (!d->pp_masks) TSU_HIP_TRY(ctx, hipMalloc(&d->pp_masks, 3 * PP_GRAN_MAX * sizeof(unsigned long long)));
     if (!d->co_corr) TSU_HIP_TRY(ctx, hipMalloc(&d->co_corr, (size_t)n * 8));
+    if (!d->co_d0) TSU_HIP_TRY(ctx, hipMalloc(&d->co_d0, (size_t)n));
     TSU_HIP_TRY(ctx, hipMemsetAsync(d->co_bar, 0, BAR_WORDS * sizeof(unsigned), ctx->stream));
     TSU_HIP_TRY(ctx, hipMemsetAsync(d->pp_masks, 0, 3 * PP_GRAN_MAX * sizeof(unsigned long long), ctx->stream));
     PipeParams P;
@@ -880,6 +859,7 @@ static int pipe_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint3
     P.uniforms = have_uni ? d->uniforms : nullptr;
     P.masks = d->pp_masks;
     P.corr = d->co_corr;
+    P.d0 = d->co_d0;
     P.bar = d->co_bar;
     P.n = n;
     P.n_sweeps = n_sweeps;
