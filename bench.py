@@ -100,6 +100,35 @@ def cpu_numpy_langevin(budget_s=2.0):
             "sample": f"d=2^20, {n} steps in {dt:.1f} s, variance {x.var():.3f}"}
 
 
+def load_counters():
+    """profiles/counters.json: per-launch PMC figures of the kernels (collected by tools/pmc_r02.sh; see its _comment)."""
+    path = os.path.join(ROOT, "profiles", "counters.json")
+    try:
+        return json.load(open(path))
+    except Exception:
+        return {}
+
+
+VALU_CYCLES_PER_WAVE_INSTRUCTION = 4.0  # one wave64 VALU instruction holds its SIMD's issue port ~4 cycles (VOP3 / packed /
+# v_perm / v_mad_u64_u32: 4.2-4.4 measured, plain VOP2 2.4-2.7: profiles/r01_microbench_instruction_cost.txt)
+N_SIMDS = 256 * 4
+
+
+def issue_roofline(entry, updates_per_launch, launch_seconds, what="spin update"):
+    """The ceiling that binds a VALU-bound kernel: wave-instructions issued per second against
+    1024 SIMDs x clock / 4 cycles.  Instruction count and clock come from the PMC passes (profiles/), the time is live."""
+    if not entry or not entry.get("valu_insts") or not entry.get("clock_ghz"):
+        return None
+    insts = float(entry["valu_insts"])
+    peak = N_SIMDS * entry["clock_ghz"] * 1e9 / VALU_CYCLES_PER_WAVE_INSTRUCTION
+    achieved = insts / launch_seconds
+    return {"bound": "valu-issue", "achieved": achieved / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s", "frac": achieved / peak,
+            f"lane_instructions_per_{what.replace(' ', '_')}": insts * 64.0 / updates_per_launch,
+            "valu_wave_instructions_per_launch": insts, "clock_ghz_in_pmc_pass": entry["clock_ghz"],
+            "cycles_per_wave_instruction_assumed": VALU_CYCLES_PER_WAVE_INSTRUCTION,
+            "note": "SQ_INSTS_VALU and GRBM_GUI_ACTIVE from profiles/counters.json (rocprofv3 --pmc passes), launch time from this run"}
+
+
 def time_lattice(hip, ctx, L, k, sweeps, reps=3, cols=None):
     rows, L = L, (cols or L)
     lat = hip.Lattice(rows, L, True, ctx=ctx)
@@ -120,7 +149,7 @@ def time_lattice(hip, ctx, L, k, sweeps, reps=3, cols=None):
             "frac_of_8TBps": 2 * ups / 1e9 / HBM_PEAK_GBS, "M": s / (rows * L), "E_per_site": -b / (rows * L)}
 
 
-def time_langevin(hip, ctx):
+def time_langevin(hip, ctx, counters):
     dim, steps = 1 << 20, 500
     out = {}
     lc = hip.LangevinChains(1, dim, ctx=ctx)
@@ -135,13 +164,38 @@ def time_langevin(hip, ctx):
         ms = ctx.timer_end()
         es = dim * steps / (ms * 1e-3)
         out[name] = {"element_steps_per_s": es, "effective_GBps_at_8B_per_element_step": 8 * es / 1e9}
+        if spl == 0:
+            # the state stays in registers for all 500 steps: real traffic is 8/500 B per element-step and the kernel is bound by
+            # instruction issue (Philox + Box-Muller), not HBM
+            out[name]["issue_roofline"] = issue_roofline(counters.get("k3_fused_d2p20_500"), dim * steps, ms * 1e-3, "element step")
+            out[name]["note"] = "effective GB/s only: the state is read and written once per launch (8.4 MB), see issue_roofline"
+        else:
+            out[name]["note"] = "4 MiB of state, 3.7 us per launch: launch-bound, not HBM-bound (the HBM-bound case is below)"
     out["variance"] = float(lc.get_state().var())  # -> T / (k (1 - k dt / 2)) = 0.505
     lc.close()
+    # the honestly HBM-bound K3 case: 256 chains x 2^20 (1 GiB of state), ONE step per launch: 8 B per element-step really move
+    chains, steps = 256, 20
+    lc = hip.LangevinChains(chains, dim, ctx=ctx)
+    lc.set_energy(2.0, 0.0)
+    lc.set_state(np.zeros((1, dim), np.float32))
+    lc.set_kernel(1)
+    lc.step(4, 0.01, 1.0, 1.0, 7, 0)
+    ctx.synchronize()
+    ctx.timer_begin()
+    lc.step(steps, 0.01, 1.0, 1.0, 7, 4)
+    ms = ctx.timer_end()
+    lc.close()
+    gbs = 8.0 * chains * dim * steps / (ms * 1e-3) / 1e9
+    tr = counters.get("k3_unfused_256x2p20", {}).get("hbm_bytes")
+    out["256_chains_one_step_per_launch"] = {
+        "element_steps_per_s": chains * dim * steps / (ms * 1e-3), "us_per_launch": ms * 1e3 / steps,
+        "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": tr,
+                     "note": "algorithmic 8 B per element-step (fp32 read + write) x 2^28 elements per launch; traffic: PMC bytes per launch"}}
     return out
 
 
-def time_dense(hip, ctx, n=16384):
-    """BASELINE configs[2]: dense Gibbs, N=16384 fp32 couplings (1 GiB of J), natural visiting order."""
+def time_dense(hip, ctx, counters, n=16384):
+    """BASELINE configs[2]: dense Gibbs, N=16384 fp32 couplings (1 GiB of J), natural visiting order (k2_pipe)."""
     rng = np.random.default_rng(42)
     G = rng.standard_normal((n, n)).astype(np.float32)
     J = ((G + G.T) / 2 / np.sqrt(n)).astype(np.float32)
@@ -151,11 +205,43 @@ def time_dense(hip, ctx, n=16384):
     d.sweep(1.0, 2, seed=1, sweep0=0)
     ctx.synchronize()
     ctx.timer_begin()
-    d.sweep(1.0, 16, seed=1, sweep0=2)  # one call: the fields are handed from sweep to sweep inside it
-    ms = ctx.timer_end() / 16
+    d.sweep(1.0, 16, seed=1, sweep0=2)  # one call = one launch: the fields are handed from sweep to sweep inside it
+    ms_call = ctx.timer_end()
+    ms = ms_call / 16
     d.close()
-    return {"N": n, "dtype": "f32", "ms_per_sweep": ms, "spin_updates_per_s": n / (ms * 1e-3),
-            "J_stream_GBps": n * n * 4 / (ms * 1e-3) / 1e9}
+    gbs = n * n * 4 / (ms * 1e-3) / 1e9
+    e = counters.get("k2_pipe_N16384_f32", {})
+    return {"N": n, "dtype": "f32", "ms_per_sweep": ms, "spin_updates_per_s": n / (ms * 1e-3), "J_stream_GBps": gbs,
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "traffic": e.get("hbm_bytes"),
+                         "note": "algorithmic N^2 x 4 B per sweep (J streamed once); the launch also reads the triangles of the first-guess "
+                                 "pass (4 x 33 MB per sweep) and one full field pass; traffic = PMC bytes of a launch of 8 sweeps "
+                                 "(profiles/r02_pmc_k2_pipe_N16384_f32.txt)"}}
+
+
+def time_sparse_chain(hip, ctx, n=1 << 24):
+    """K5: colour-parallel sweeps of a 2^24-site open chain (the reference's IsingChain would need a 2 PB dense J)."""
+    import scipy.sparse as sp
+    from tsu.graph import canonical_csr
+    A = canonical_csr(sp.diags([np.full(n - 1, 4.0), np.full(n - 1, 4.0)], [1, -1]))
+    bias = np.full(n, -8.0)
+    bias[0] = bias[-1] = -4.0
+    order = np.concatenate([np.arange(0, n, 2), np.arange(1, n, 2)]).astype(np.int32)
+    g = hip.SparseSystem(A.indptr, A.indices, A.data, bias, np.array([0, (n + 1) // 2, n], np.int32), order, ctx=ctx)
+    g.set_state(np.random.default_rng(1).integers(0, 2, size=n).astype(np.int8))
+    g.sweep(1.7, 5, seed=3, sweep0=0)
+    ctx.synchronize()
+    ctx.timer_begin()
+    g.sweep(1.7, 50, seed=3, sweep0=5)
+    ms = ctx.timer_end() / 50
+    _, m = g.energy()
+    g.close()
+    alg = 17 + 13 * 2  # bytes per update: row extent 8 + bias 8 + state write 1, per neighbour column 4 + coupling 8 + bit 1
+    gbs = alg * n / (ms * 1e-3) / 1e9
+    return {"sites": n, "ms_per_sweep": ms, "spin_updates_per_s": n / (ms * 1e-3),
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                         "note": "algorithmic 17 + 13 deg bytes per update (CSR gather kernel, deg = 2)"},
+            "M": m / n}
 
 
 def build_parser():
@@ -255,9 +341,8 @@ def main():
     rows_local = L // world if (args.strong and world > 1) else L  # rows of this rank's slab
     if args.strong and world > 1 and L % world:
         raise SystemExit("--strong needs L divisible by the number of GPUs")
-    k = args.sweeps_per_launch or (8 if rows_local * L <= 4096 * 4096 else 5)
-    if args.strong and world > 1 and not args.sweeps_per_launch:
-        k = 8  # thin slabs run 256-row tiles, one per CU (tools/shape_scan.py)
+    # sweeps per generation / launch: the library's own choice (8: one halo octet = 16 columns covers 2 x 8 half-sweeps) unless asked
+    k = args.sweeps_per_launch or 8
     # sweeps per halo exchange (tools/slab_rate.py: a 4096^2 slab does 2.55e12 upd/s at 64, 2.71e12 at 96..128, 2.62e12 at 192:
     # fewer launches and exchanges against taller tiles on the deep ghost rows; thin strong-scaling slabs: 32)
     spx = args.sweeps_per_exchange or (32 if (args.strong and world > 1) else k * round(128 / k))
@@ -269,7 +354,7 @@ def main():
         lat = hip.Lattice(L, L, True, ctx=ctx)
         lat.randomize(42)
         lat.set_model(1.0, 0.0, T_C, hip.MODE_PHYSICAL)
-        lat.set_kernel(hip.KERNEL_AUTO, k)
+        lat.set_kernel(hip.KERNEL_AUTO, args.sweeps_per_launch)
         state = {"sweep": 0}
 
         def step():
@@ -329,14 +414,15 @@ def main():
     # 2 * sites * s bytes
     alg_bytes_per_launch = 2.0 * rows_local * L * sweeps_per_launch_avg
     achieved = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            key = (f"k1_resident_L{L}_s{int(round(sweeps_per_launch_avg))}" if sweeps_per_launch_avg > k else f"k1_tiled_L{L}_k{k}")
-            traffic = json.load(open(tpath)).get(key)
-        except Exception:
-            traffic = None
+    counters = load_counters()
+    resident = sweeps_per_launch_avg > k
+    # nibble colour planes: whole periodic lattices above 2^25 sites (csrc/ising2d_tiled.hip: pick_variant)
+    nib = world == 1 and L % 16 == 0 and L * L > (1 << 25) and os.environ.get("TSU_K1_NIBBLE", "1") != "0"
+    ckey = (f"k1_resident{'_nib' if nib else ''}_L{L}_s{int(round(sweeps_per_launch_avg))}" if resident
+            else f"k1_tiled{'_nib' if nib else ''}_L{L}_k{int(round(sweeps_per_launch_avg))}")
+    centry = counters.get(ckey) if world == 1 else None
+    traffic = centry.get("hbm_bytes") if centry else None
+    issue = issue_roofline(centry, float(rows_local) * L * sweeps_per_launch_avg, avg_launch_ms * 1e-3) if centry else None
 
     if world == 1:
         s, b = lat.observables()
@@ -353,15 +439,18 @@ def main():
             "config": {"workload": f"IsingModel2D {rows_local}x{L} per GPU at T_c=2.269185, J=1, h=0, periodic, checkerboard Gibbs sweep "
                                    "(BASELINE.json configs[1])", "L": L, "lattice_rows": rows_local * world, "lattice_cols": L,
                        "sweeps_per_step": sps, "sweeps_per_generation": k, "sweeps_per_launch": sweeps_per_launch_avg, "sweeps_per_exchange": spx if world > 1 else None,
-                       "clock_ramp_steps_before_warmup": args.ramp_steps, "kernel": "k1_resident (tiles stay in LDS across generations of k sweeps, boundary strips exchanged through HBM)"
-                                 if sweeps_per_launch_avg > k else "k1_tiled2 (LDS halo tiles, row-pair inner loop)",
+                       "clock_ramp_steps_before_warmup": args.ramp_steps,
+                       "kernel": ("k1_resident (tiles stay in LDS across generations of k sweeps, boundary strips exchanged through HBM)"
+                                  if resident else "k1_tiled2 (LDS halo tiles, row-pair inner loop)") + (", nibble colour planes" if nib else ""),
+                       "counters_key": ckey if centry else None,
                        "bias_mode": "physical", "parallelism": parallelism, "launches": n_launches,
                        "avg_launch_us": avg_launch_ms * 1e3, "algorithmic_bytes_per_launch": alg_bytes_per_launch},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "note": "achieved = algorithmic 2 B/spin-update x sites x sweeps per launch / avg launch time (HIP events "
                                  "on the launch stream over the timed region); tiles live in LDS for many sweeps, so real "
-                                 "HBM traffic is a small fraction of that and the kernel is VALU (Philox) bound"},
+                                 "HBM traffic is a small fraction of that and the kernel is VALU (Philox) bound: see issue_roofline"},
+            "issue_roofline": issue,
             "observables": {"M": s / (float(rows_local) * L * world), "E_per_site": -b / (float(rows_local) * L * world),
                             "note": "physical mode, random start; u(T_c) = -sqrt(2) = -1.4142 is approached slowly (critical slowing down)"},
         }
@@ -382,8 +471,9 @@ def main():
             extra["ising2d_32x32"] = time_lattice(hip, ctx, 32, 0, 20000)
             # a width that is not a multiple of 16 (the wrap falls inside an octet): IsingModel2D(1000)
             extra["ising2d_1000x1000"] = time_lattice(hip, ctx, 1000, 0, 4096)
-            extra["langevin_dim_2^20"] = time_langevin(hip, ctx)
-            extra["dense_gibbs"] = time_dense(hip, ctx)
+            extra["langevin_dim_2^20"] = time_langevin(hip, ctx, counters)
+            extra["dense_gibbs"] = time_dense(hip, ctx, counters)
+            extra["sparse_chain_2^24"] = time_sparse_chain(hip, ctx)
             out["extra"] = extra
         print(json.dumps(out))
     if world > 1:

@@ -9,6 +9,6 @@ J = ((G + G.T) / 2 / np.sqrt(n)).astype(np.float32)
 np.fill_diagonal(J, 0.0)
 d = hip.DenseSystem(J, None, hip.DTYPE_F32, ctx=ctx)
 d.set_state(rng.integers(0, 2, size=n).astype(np.int8))
-d.sweep(1.0, 3, seed=1, sweep0=0)
+d.sweep(1.0, int(sys.argv[2]) if len(sys.argv) > 2 else 3, seed=1, sweep0=0)
 ctx.synchronize()
 d.close()
