@@ -46,3 +46,18 @@ def test_pipeline_long_call_hands_fields_from_sweep_to_sweep(n):
         np.testing.assert_array_equal(d.get_state(), want)
     assert abs(d.energy() - ora.c_dense_energy(want.astype(np.int64), J.astype(np.float64))) < 1e-6 * n
     d.close()
+
+
+def test_pipeline_replays_numpy_uniforms():
+    """rng="numpy" at a size the pipeline takes: the kernel consumes the caller's np.random.rand() doubles in visiting order
+    (gibbs.py:126) and must return the reference loop's states (oracle: C replay of the sequential loop)."""
+    from tsu import _hip
+    n, k = 2048, 3
+    J, b, s0 = _system(n, 5, f64=True)
+    u = np.random.default_rng(9).random((k, n))
+    d = _hip.DenseSystem(J, b, _hip.DTYPE_F64)
+    d.set_state(s0)
+    d.sweep(0.9, k, replay_uniforms=u)
+    want = ora.c_dense_sweep_replay(s0.astype(np.int64), J, b, 0.9, u)
+    np.testing.assert_array_equal(d.get_state(), want.astype(np.int8))
+    d.close()
