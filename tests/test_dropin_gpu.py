@@ -512,3 +512,42 @@ def test_specific_heat_of_a_samples_array_matches_the_reference(golden):
     gg = IsingGrid((4, 6), J=0.8, config=IsingConfig(temperature=1.9, external_field=0.25), periodic=True)
     assert abs(gg.specific_heat(g6["grid_samples"]) - float(g6["grid_C"])) < 1e-12
     np.testing.assert_allclose([gg.energy(s) for s in g6["grid_samples"]], g6["grid_E"], rtol=0, atol=1e-12)
+
+
+def test_hardware_emulator_chains_advance_together_and_equal_the_loop():
+    """HardwareEmulator.sample_parallel (gibbs.py:450-487): the chain loop runs as one device call per sweep group; the
+    samples are those of the reference's loop of sample_boltzmann calls on one sampler (same np.random and Philox draws)."""
+    from tsu.gibbs import GibbsConfig, GibbsSampler, HardwareEmulator
+    rng = np.random.default_rng(3)
+    for n in (10, 70, 300):
+        J = rng.normal(size=(n, n)) / np.sqrt(n)
+        J = (J + J.T) / 2
+        np.random.seed(11)
+        a = GibbsSampler(GibbsConfig(temperature=1.2, n_burnin=5, n_sweeps=2), seed=99)
+        loop = np.array([a.sample_boltzmann(J, n_samples=3, burnin=4) for _ in range(6)])
+        np.random.seed(11)
+        b = GibbsSampler(GibbsConfig(temperature=1.2, n_burnin=5, n_sweeps=2), seed=99)
+        together = b.sample_chains(J, 6, 3, burnin=4)
+        np.testing.assert_array_equal(together, loop)
+        assert b.sample_count == a.sample_count == 18 and b._sweep_counter == a._sweep_counter
+    hw = HardwareEmulator(n_bits=10, parallel_chains=50)
+    np.random.seed(1)
+    samples, timing = hw.sample_parallel(np.zeros((10, 10)), n_samples=120, temperature=1.0)
+    assert samples.shape == (120, 10) and set(np.unique(samples)) <= {0, 1} and abs(samples.mean() - 0.5) < 0.06
+    assert timing["batches_needed"] == 3
+
+
+def test_parallel_tempering_mid_size_system_in_one_device_call_per_step():
+    """parallel_tempering on 100 sites (beyond one wave's 64): all replicas in one call per step, results equal the reference
+    control flow run replica by replica (random order path, which still loops) in distribution: low-T replica has lower energy."""
+    from tsu.gibbs import GibbsConfig, GibbsSampler
+    n = 100
+    J = np.zeros((n, n))
+    for i in range(n - 1):
+        J[i, i + 1] = J[i + 1, i] = 1.0
+    np.random.seed(4)
+    s = GibbsSampler(GibbsConfig(temperature=1.0, n_burnin=20, n_sweeps=2), seed=5)
+    samples, info = s.parallel_tempering(J, [0.3, 1.0, 3.0], n_samples=40, swap_interval=5)
+    assert samples.shape == (40, n) and info["swap_attempts"] == 16
+    e = np.array(info["energies"])
+    assert e.shape == (3, 40) and e[0, 10:].mean() < e[1, 10:].mean() < e[2, 10:].mean()

@@ -320,6 +320,42 @@ class GibbsSampler:
         self._sweep_counter += total
         return out
 
+    def sample_chains(self, coupling: np.ndarray, n_chains: int, n_samples_per_chain: int, bias: Optional[np.ndarray] = None,
+                      burnin: Optional[int] = None) -> np.ndarray:
+        """``n_chains`` consecutive ``sample_boltzmann(coupling, bias, n_samples_per_chain, burnin)`` calls of THIS sampler --
+        the chain loop of ``HardwareEmulator.sample_parallel`` (reference: gibbs.py:470-478) -- with all chains advanced
+        together on the device (one wave / workgroup per chain, ``tsu_dense_sweep_replicas``).  Same draws as the loop: every
+        chain's initial state comes from ``np.random.randint`` in chain order, chain c uses the Philox sweep numbers the c-th
+        call would have used.  Returns ``(n_chains, n_samples_per_chain, n_bits)``; ``sample_count`` advances as in the loop."""
+        coupling = np.asarray(coupling)
+        n_bits = coupling.shape[0]
+        if coupling.shape != (n_bits, n_bits):
+            raise ValueError("Coupling matrix must be square")
+        burnin = int(self.config.n_burnin if burnin is None else burnin)
+        n_sweeps, T = int(self.config.n_sweeps), float(self.config.temperature)
+        if self.rng != "philox" or self.config.update_order != "sequential" or n_chains < 2:
+            return np.array([self.sample_boltzmann(coupling, bias, n_samples_per_chain, burnin) for _ in range(n_chains)])
+        if T <= 0:
+            raise ValueError("Temperature must be positive")
+        per_chain = burnin + n_samples_per_chain * n_sweeps
+        sys = self._system(coupling, bias)
+        seed = self._philox_seed()
+        out = np.zeros((n_chains, n_samples_per_chain, n_bits), dtype=int)
+        batch = max(1, min(n_chains, (1 << 26) // max(1, n_bits)))  # <= 64 MiB of chain states in flight
+        for c0 in range(0, n_chains, batch):
+            m = min(batch, n_chains - c0)
+            states = np.array([np.random.randint(0, 2, size=n_bits) for _ in range(m)], dtype=np.int8)
+            base = np.array([self._sweep_counter + (c0 + c) * per_chain for c in range(m)], dtype=np.uint32)
+            temps, seeds = [T] * m, [seed] * m
+            if burnin:
+                states = sys.sweep_replicas(states, temps, burnin, seeds, base)
+            for k in range(n_samples_per_chain):
+                states = sys.sweep_replicas(states, temps, n_sweeps, seeds, base + np.uint32(burnin + k * n_sweeps))
+                out[c0:c0 + m, k] = states
+        self._sweep_counter += n_chains * per_chain
+        self.sample_count += n_chains * n_samples_per_chain
+        return out
+
     def sample(self, J: np.ndarray, n_samples: int = 1000, bias: Optional[np.ndarray] = None) -> np.ndarray:
         """README name (README.md:79) for :meth:`sample_boltzmann`."""
         return self.sample_boltzmann(J, bias=bias, n_samples=n_samples)
@@ -361,7 +397,7 @@ class GibbsSampler:
         # arrays cannot change under it (restored / dropped at the end)
         held_before = self._held
         self.bind(coupling, bias)
-        if n_bits > 64 or self.config.update_order != "sequential":
+        if self.config.update_order != "sequential":
             for rep in samplers:
                 rep.bind(coupling, bias)
         try:
@@ -407,13 +443,14 @@ class GibbsSampler:
 
     def _sweep_replicas(self, samplers, states, coupling, bias, n_sweeps):
         """The replica loop of parallel_tempering (reference: gibbs.py:300-306): every replica's sweeps in ONE device
-        call for systems of up to 64 sites in sequential order (one wave per replica); otherwise replica by replica.
+        call in sequential order (one wave per replica up to 192 / 128 sites, one workgroup per replica up to 576 / 448, larger
+        systems replica after replica on the device side, all from ONE device copy of J); random order: replica by replica.
         Draws (np.random uniforms / each replica's Philox counters) are consumed exactly as in the one-by-one loop."""
         n_sweeps = int(n_sweeps)
         n_bits = np.asarray(coupling).shape[0]
         if n_sweeps <= 0:
             return states
-        if n_bits > 64 or self.config.update_order != "sequential":
+        if self.config.update_order != "sequential":
             return [s.gibbs_sweep(st, coupling, bias, n_sweeps=n_sweeps) for s, st in zip(samplers, states)]
         sys = self._system(coupling, bias)
         temps = [float(s.config.temperature) for s in samplers]
@@ -557,9 +594,8 @@ class HardwareEmulator:
         config = GibbsConfig(temperature=temperature)
         sampler = GibbsSampler(config)
         samples_per_chain = int(np.ceil(n_samples / self.parallel_chains))
-        all_samples = []
-        for _ in range(min(self.parallel_chains, n_samples)):
-            all_samples.append(sampler.sample_boltzmann(coupling, n_samples=samples_per_chain, burnin=100))
-        samples = np.vstack(all_samples)[:n_samples]
+        # the reference's loop of independent chains (gibbs.py:470-478), all chains advanced together on the device
+        chains = sampler.sample_chains(coupling, min(self.parallel_chains, n_samples), samples_per_chain, burnin=100)
+        samples = chains.reshape(-1, chains.shape[-1])[:n_samples]
         timing = self.estimate_hardware_time(n_samples, config.n_sweeps)
         return samples, timing
