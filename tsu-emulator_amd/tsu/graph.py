@@ -24,7 +24,7 @@ def color_graph(A: sp.csr_matrix, max_colors: int = 64) -> Tuple[np.ndarray, np.
 
     Returns ``(color_offsets, order)``: ``order`` lists the sites colour by colour (ascending site number inside a
     colour), ``color_offsets[c]:color_offsets[c+1]`` delimits colour c.  Bipartite graphs (chains, trees, even rings,
-    open square lattices) get their 2-colouring from a breadth-first search; other graphs a vectorised
+    open square lattices) get their 2-colouring from the components of the bipartite double cover; other graphs a vectorised
     independent-set colouring (Luby rounds with random priorities, fixed seed: reproducible)."""
     n = A.shape[0]
     P = sp.csr_matrix((np.ones(A.nnz, dtype=np.int8), A.indices, A.indptr), shape=A.shape)
@@ -32,37 +32,16 @@ def color_graph(A: sp.csr_matrix, max_colors: int = 64) -> Tuple[np.ndarray, np.
     P.setdiag(0)
     P.eliminate_zeros()
     color = np.full(n, -1, dtype=np.int64)
-    # --- bipartite attempt: BFS depth parity per connected component
-    n_comp, labels = csgraph.connected_components(P, directed=False)
-    depth = np.zeros(n, dtype=np.int64)
-    seen = np.zeros(n, dtype=bool)
-    roots = np.full(n_comp, -1, dtype=np.int64)
-    first = np.unique(labels, return_index=True)[1]
-    roots[labels[first]] = first
-    if n_comp > max(1024, n // 4):
-        # many tiny components (mostly isolated sites): isolated sites need no search
-        deg = np.diff(P.indptr)
-        seen[deg == 0] = True
-    for r in roots:
-        if seen[r]:
-            continue
-        nodes, pred = csgraph.breadth_first_order(P, int(r), directed=False, return_predecessors=True)
-        d = np.zeros(nodes.size, dtype=np.int64)
-        # nodes come in BFS order: a predecessor always precedes its children
-        idx = {int(v): k for k, v in enumerate(nodes)} if nodes.size < 64 else None
-        if idx is not None:
-            for k, v in enumerate(nodes[1:], 1):
-                d[k] = d[idx[int(pred[v])]] + 1
-            depth[nodes] = d
-        else:
-            dep = np.zeros(n, dtype=np.int64)
-            for v in nodes[1:]:
-                dep[v] = dep[pred[v]] + 1
-            depth[nodes] = dep[nodes]
-        seen[nodes] = True
-    two = depth & 1
     rows = np.repeat(np.arange(n), np.diff(P.indptr))
-    if not np.any(two[rows] == two[P.indices]):
+    # --- bipartite attempt, one pass for any number of components: in the bipartite double cover (nodes (i, 0), (i, 1), an edge
+    # (i, a) - (j, 1 - a) for every edge i - j) a bipartite component of the graph splits into its two colour classes, a
+    # non-bipartite one stays connected.  colour(i) = [component of (i, 0) > component of (i, 1)] is then a proper 2-colouring.
+    cover = sp.bmat([[None, P], [P, None]], format="csr") if P.nnz else sp.csr_matrix((2 * n, 2 * n))
+    _, lab = csgraph.connected_components(cover, directed=False)
+    l0, l1 = lab[:n], lab[n:]
+    if not np.any((l0 == l1) & (np.diff(P.indptr) > 0)):
+        two = (l0 > l1).astype(np.int64)
+        two[np.diff(P.indptr) == 0] = 0          # isolated sites: colour 0
         color = two
     else:
         # --- general graph: repeated maximal-independent-set extraction
