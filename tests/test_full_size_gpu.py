@@ -82,6 +82,31 @@ def test_config2_lattice_8192_kernels_agree(hip):
     assert -1.42 < -sums[0][1][1] / (L * L) < -1.25
 
 
+@pytest.mark.parametrize("rows,cols,sweeps", [(16384, 4096, (19, 8)),    # 2^26 sites: 256 nibble-plane tiles of 512 x 512, resident
+                                              (5888, 6144, (9, 3)),      # ragged tile rows: 256 x 512 nibble tiles, one launch per 8 sweeps
+                                              (8192, 16384, (11,))])     # 2^27 sites, whole tiles
+def test_nibble_plane_lattices_chosen_automatically_equal_the_generic_kernel(hip, rows, cols, sweeps):
+    """Lattices above 2^25 sites take the nibble colour planes (csrc/ising2d_tiled.hip: pick_variant): the automatic choice
+    must give the generic kernel's lattice, by checksum and observables, over several calls (sweep counters run on)."""
+    lats = []
+    for kern in (hip.KERNEL_AUTO, hip.KERNEL_GENERIC):
+        lat = hip.Lattice(rows, cols, True)
+        lat.set_kernel(kern)
+        lat.randomize(13)
+        lat.set_model(1.0, -0.01, T_C)
+        lats.append(lat)
+    done = 0
+    for n in sweeps:
+        res = []
+        for lat in lats:
+            lat.sweep(n, 13, sweep0=done)
+            res.append((zlib.crc32(lat.get_spins().tobytes()), lat.observables()))
+        done += n
+        assert res[0] == res[1], (rows, cols, done)
+    for lat in lats:
+        lat.close()
+
+
 def test_config4_16384_as_eight_slabs_equals_one_lattice(hip):
     """configs[3]: 16384 x 16384 cut into 8 row slabs of 2048 x 16384 (ghost rows refreshed by the test every 8 sweeps,
     the exchange RCCL performs between ranks) == the same lattice swept whole.  Row checksums compared per slab."""
