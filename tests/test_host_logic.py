@@ -71,6 +71,12 @@ def test_product_path_fails_loudly_without_gpu():
 
 
 def test_product_never_imports_the_oracle():
+    # the measurement / development scripts under tools/ stay clear of the oracle too: only tests/, smoke() and bench.py's
+    # cpu_baseline leg use it
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith((".py", ".sh")):
+            text = open(os.path.join(ROOT, "tools", f)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M) and "libtsu_oracle" not in text, f
     pkg = os.path.join(ROOT, "tsu-emulator_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
