@@ -62,7 +62,19 @@ bool tsu_use_coop_launch() {
 
 hipError_t tsu_launch_grid_sync(tsu_ctx* ctx, const void* kernel, dim3 grid, dim3 block, void* param_struct, size_t lds_bytes, hipStream_t stream) {
     void* args[] = {param_struct};
-    if (tsu_use_coop_launch() && !ctx->in_batch) return hipLaunchCooperativeKernel(kernel, grid, block, args, (unsigned)lds_bytes, stream);
+    if (tsu_use_coop_launch() && !ctx->in_batch) {
+        const hipError_t e = hipLaunchCooperativeKernel(kernel, grid, block, args, (unsigned)lds_bytes, stream);
+        if (e == hipSuccess) return e;
+        // the runtime declined (a device / driver without cooperative launch, or its own residency arithmetic disagrees with the
+        // occupancy query the caller sized the grid from): say so once and launch the same grid the ordinary way -- the
+        // kernels' bounded waits still turn a grid that is not co-resident into an error instead of a hang
+        static bool told = false;
+        if (!told) {
+            fprintf(stderr, "[tsu] hipLaunchCooperativeKernel: %s; using ordinary launches for grid-synchronising kernels\n", hipGetErrorString(e));
+            told = true;
+        }
+        (void)hipGetLastError();
+    }
     return hipLaunchKernel(kernel, grid, block, args, lds_bytes, stream);
 }
 
