@@ -367,7 +367,9 @@ def main():
         parallelism = "single GPU"
     else:
         # one halo exchange per spx sweeps; the slab keeps its own halo exact in between (deep ghost rows)
-        slab = SlabLattice(rows_local, L, periodic=True, sweeps_per_exchange=spx, seed=42)
+        # BENCH_TRANSPORT=rccl: the halo travels through the library's own RCCL calls below the C ABI (tsu_ising2d_halo_exchange)
+        # instead of torch.distributed's point-to-point ops (the default)
+        slab = SlabLattice(rows_local, L, periodic=True, sweeps_per_exchange=spx, seed=42, transport=os.environ.get("BENCH_TRANSPORT", "torch"))
         slab.lat.set_kernel(hip.KERNEL_AUTO, k)
         slab.randomize()
         slab.set_model(1.0, 0.0, T_C, hip.MODE_PHYSICAL)
@@ -436,6 +438,7 @@ def main():
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong" if (args.strong and world > 1) else "weak", "vs_baseline": None,
             "dtype": "int8", "data": "synthetic (Philox i.i.d. +-1 start, seed 42)",
             "backend": backend if world > 1 else None, "ranks_seen": world, "gpus_requested": args.gpus,
+            "halo_transport": (os.environ.get("BENCH_TRANSPORT", "torch") if world > 1 else None),
             "config": {"workload": f"IsingModel2D {rows_local}x{L} per GPU at T_c=2.269185, J=1, h=0, periodic, checkerboard Gibbs sweep "
                                    "(BASELINE.json configs[1])", "L": L, "lattice_rows": rows_local * world, "lattice_cols": L,
                        "sweeps_per_step": sps, "sweeps_per_generation": k, "sweeps_per_launch": sweeps_per_launch_avg, "sweeps_per_exchange": spx if world > 1 else None,

@@ -33,7 +33,7 @@ extern "C" {
 #define TSU_E_INVALID (-1)     /* bad argument (Python side raises ValueError / ConfigurationError) */
 #define TSU_E_NOMEM (-2)       /* host or device allocation failed */
 #define TSU_E_HIP (-3)         /* a HIP runtime call failed */
-#define TSU_E_RCCL (-4)        /* reserved: collective failure */
+#define TSU_E_RCCL (-4)        /* RCCL not loadable / a communicator call failed */
 #define TSU_E_UNSUPPORTED (-5) /* valid request this build has no kernel for */
 
 #define TSU_MODE_PHYSICAL 0 /* corrected spin->bit bias: P(+1) = sigmoid(2 (J nsum + h) / T) */
@@ -52,6 +52,7 @@ typedef struct tsu_ising2d tsu_ising2d;
 typedef struct tsu_dense tsu_dense;
 typedef struct tsu_langevin tsu_langevin;
 typedef struct tsu_sparse tsu_sparse;
+typedef struct tsu_comm tsu_comm;
 
 /* ------------------------------------------------------------------ context */
 int tsu_version(void);
@@ -150,6 +151,22 @@ int tsu_ising2d_set_timing(tsu_ising2d* lat, int enable);
 int tsu_ising2d_last_sweep_ms(tsu_ising2d* lat, float* ms);
 /* sweep-kernel launches issued for this lattice so far (a tile-resident launch runs many generations of sweeps) */
 int tsu_ising2d_launch_count(tsu_ising2d* lat, uint64_t* n_launches);
+
+/* ------------------------------------------------------------------ multi-GPU: RCCL below the ABI
+ * One process per GPU.  A lattice that does not fit (or should not be swept by) one GPU is cut into row slabs
+ * (tsu_ising2d_create_slab); these entry points refresh the ghost rows from the neighbouring ranks with RCCL send/recv over
+ * xGMI and sum observables over the ranks -- no PyTorch involved (tsu/distributed.py offers the same through torch.distributed).
+ * RCCL is dlopen'ed on first use.  The reference has no counterpart (it is a single Python thread). */
+/* 128 opaque bytes, created on ONE rank and handed to the others by the caller (file, environment, MPI, torch.distributed ...) */
+int tsu_comm_unique_id(uint8_t id[128]);
+/* collective: every rank calls it with the same id; the communicator works on ctx's device and stream */
+int tsu_comm_create(tsu_ctx* ctx, int nranks, int rank, const uint8_t id[128], tsu_comm** out);
+int tsu_comm_destroy(tsu_comm* comm);
+/* ghost rows of slab `rank` <- boundary rows of ranks rank-1 / rank+1 (wrapping for a periodic lattice), one RCCL group on the
+ * ctx stream; asynchronous like the sweeps it is ordered with.  The slab must be rows * nranks == total_rows, row0 == rows * rank. */
+int tsu_ising2d_halo_exchange(tsu_ising2d* lat, tsu_comm* comm);
+/* values[i] <- sum over ranks (n <= 8; observables: sum of spins, sum over bonds); synchronises */
+int tsu_comm_allreduce_i64(tsu_comm* comm, int64_t* values, int n);
 
 /* ------------------------------------------------------------------ dense coupling matrix (K2)
  * Replaces GibbsSampler.gibbs_sweep / sample_boltzmann / compute_energy on a dense J

@@ -167,3 +167,73 @@ def test_bench_gpus_2_on_this_box_is_never_reported_as_one_gpu():
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
         out = json.loads(line)
         assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["backend"] == "nccl"
+
+
+# ------------------------------------------------------------------ RCCL below the C ABI (tsu_comm_*, tsu_ising2d_halo_exchange)
+def test_c_abi_rccl_transport_one_rank_is_its_own_neighbour():
+    """transport="rccl": the halo exchange is the library's own RCCL group (send/recv to the rank above and below; with one
+    rank both are this rank) and the observables go through ncclAllReduce -- no torch.distributed anywhere."""
+    from tsu import _hip
+    from tsu.distributed import SlabLattice
+    rows, cols, k, seed = 256, 1024, 8, 33
+    lat = SlabLattice(rows, cols, periodic=True, sweeps_per_exchange=k, seed=seed, transport="rccl")
+    assert lat.comm is not None and not lat.distributed
+    lat.randomize()
+    lat.set_model(1.0, 0.0, 2.269185, _hip.MODE_PHYSICAL)
+    lat.sweep(2 * k + 3)
+    lat.synchronize()
+    table = ora.ising2d_thresholds(1.0, 0.0, 2.269185, 0)
+    want = ora.ising2d_sweep(ora.ising2d_randomize(rows, cols, seed), True, table, 2 * k + 3, seed)
+    np.testing.assert_array_equal(lat.gather_spins(), want)
+    assert lat.observables() == ora.ising2d_observables(want, True)
+    # an open slab has no neighbours at world size 1: the exchange is an empty group
+    op = SlabLattice(128, 512, periodic=False, sweeps_per_exchange=4, seed=5, transport="rccl")
+    op.randomize()
+    op.set_model(1.0, 0.1, 2.0, _hip.MODE_PHYSICAL)
+    op.sweep(6)
+    want = ora.ising2d_sweep(ora.ising2d_randomize(128, 512, 5), False, ora.ising2d_thresholds(1.0, 0.1, 2.0, 0), 6, 5)
+    np.testing.assert_array_equal(op.gather_spins(), want)
+
+
+def test_c_abi_rccl_transport_two_ranks():
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nccl_worker_abi, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full, obs = q.get(timeout=300)
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs)
+    table = ora.ising2d_thresholds(1.0, 0.0, 2.269185, 0)
+    want = ora.ising2d_sweep(ora.ising2d_randomize(512, 1024, 21), True, table, 19, 21)
+    np.testing.assert_array_equal(full, want)
+    assert obs == ora.ising2d_observables(want, True)
+
+
+def _nccl_worker_abi(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tsu-emulator_amd"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    from tsu import _hip
+    from tsu.distributed import SlabLattice
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, device_id=torch.device(f"cuda:{rank}"))
+    try:
+        lat = SlabLattice(256, 1024, periodic=True, sweeps_per_exchange=8, seed=21, device=rank, transport="rccl")
+        lat.randomize()
+        lat.set_model(1.0, 0.0, 2.269185, _hip.MODE_PHYSICAL)
+        lat.sweep(19)
+        obs = lat.observables()
+        full = lat.gather_spins()
+        if rank == 0:
+            q.put((full, obs))
+    finally:
+        dist.destroy_process_group()

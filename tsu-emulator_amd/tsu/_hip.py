@@ -75,6 +75,11 @@ SIGNATURES = {
     "tsu_ising2d_set_timing": (C.c_int, [_vp, C.c_int]),
     "tsu_ising2d_last_sweep_ms": (C.c_int, [_vp, _f32p]),
     "tsu_ising2d_launch_count": (C.c_int, [_vp, _u64p]),
+    "tsu_comm_unique_id": (C.c_int, [_u8p]),
+    "tsu_comm_create": (C.c_int, [_vp, C.c_int, C.c_int, _u8p, C.POINTER(_vp)]),
+    "tsu_comm_destroy": (C.c_int, [_vp]),
+    "tsu_ising2d_halo_exchange": (C.c_int, [_vp, _vp]),
+    "tsu_comm_allreduce_i64": (C.c_int, [_vp, _i64p, C.c_int]),
     "tsu_dense_create": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _f64p, C.POINTER(_vp)]),
     "tsu_dense_destroy": (C.c_int, [_vp]),
     "tsu_dense_set_state": (C.c_int, [_vp, _i8p]),
@@ -178,6 +183,8 @@ class Context:
             raise UnsupportedError(msg)
         if rc == TSU_E_NOMEM:
             raise MemoryError(msg)
+        if rc == TSU_E_RCCL:
+            raise HipError(f"RCCL: {msg}")
         raise HipError(f"libtsu_hip error {rc}: {msg}")
 
     def set_stream(self, stream_ptr):
@@ -424,6 +431,48 @@ class DenseSystem:
         e = C.c_double(0)
         self.ctx.check(self.lib.tsu_dense_energy(self.h, C.byref(e)))
         return e.value
+
+
+def comm_unique_id() -> bytes:
+    """128 opaque bytes that identify a new RCCL communicator: create on one rank, hand to the others."""
+    lib = load_library()
+    buf = np.zeros(128, dtype=np.uint8)
+    rc = lib.tsu_comm_unique_id(_ptr(buf, _u8p))
+    if rc != TSU_OK:
+        raise HipError(f"tsu_comm_unique_id failed ({rc}): {lib.tsu_last_error(None).decode()}")
+    return buf.tobytes()
+
+
+class Comm:
+    """tsu_comm handle: an RCCL communicator below the C ABI (one rank = one process = one GPU)."""
+
+    def __init__(self, nranks, rank, unique_id: bytes, ctx=None):
+        self.ctx = ctx or Context.default()
+        self.lib = self.ctx.lib
+        self.nranks, self.rank = int(nranks), int(rank)
+        uid = np.frombuffer(unique_id, dtype=np.uint8).copy()
+        if uid.size != 128:
+            raise ValueError("the unique id is 128 bytes")
+        h = _vp()
+        self.ctx.check(self.lib.tsu_comm_create(self.ctx.h, self.nranks, self.rank, _ptr(uid, _u8p), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tsu_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self, _finalizing=sys.is_finalizing):
+        if not _finalizing():
+            self.close()
+
+    def halo_exchange(self, lattice: "Lattice"):
+        self.ctx.check(self.lib.tsu_ising2d_halo_exchange(lattice.h, self.h))
+
+    def allreduce(self, values):
+        v = np.ascontiguousarray(values, dtype=np.int64).copy()
+        self.ctx.check(self.lib.tsu_comm_allreduce_i64(self.h, _ptr(v, _i64p), v.size))
+        return v
 
 
 class SparseSystem:

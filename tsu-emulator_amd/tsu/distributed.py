@@ -43,7 +43,8 @@ class SlabLattice:
     """
 
     def __init__(self, rows_per_rank: int, cols: int, periodic: bool = True, sweeps_per_exchange: int = 4,
-                 seed: int = 0, group=None, engine=None, overlap: bool = False, device: Optional[int] = None):
+                 seed: int = 0, group=None, engine=None, overlap: bool = False, device: Optional[int] = None,
+                 transport: str = "torch"):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -62,7 +63,9 @@ class SlabLattice:
         self.sweep_count = 0
         self.up = (self.rank - 1) % self.world if (self.periodic or self.rank > 0) else None
         self.down = (self.rank + 1) % self.world if (self.periodic or self.rank < self.world - 1) else None
-        self._host_staged = engine is not None or self.backend == "gloo"  # ghosts staged through host memory
+        # ghosts staged through host memory: test doubles, and torch's gloo backend -- unless the library's own RCCL transport
+        # moves them (then gloo, if a process group exists at all, only carries the communicator's id)
+        self._host_staged = engine is not None or (self.backend == "gloo" and transport != "rccl")
         if engine is None:
             ctx = _hip.Context.default() if device is None else _hip.Context(device)
             self.ctx = ctx
@@ -78,6 +81,27 @@ class SlabLattice:
             self.lat = engine(self.rows, self.cols, self.periodic, total_rows=self.total_rows, row0=self.rank * self.rows,
                               ghost=self.ghost)
             self.comm_stream = None
+        # transport of the ghost rows between GPUs: "torch" = torch.distributed point-to-point ops (RCCL under the nccl backend);
+        # "rccl" = the library's own RCCL calls below the C ABI (tsu_ising2d_halo_exchange; torch.distributed, if initialised,
+        # only carries the communicator's 128-byte id from rank 0 to the others)
+        if transport not in ("torch", "rccl"):
+            raise ValueError("transport must be 'torch' or 'rccl'")
+        self.transport = transport
+        self.comm = None
+        if transport == "rccl":
+            if engine is not None:
+                raise ValueError("transport='rccl' moves device buffers: it needs the HIP lattice")
+            if self.distributed:
+                uid = torch.zeros(128, dtype=torch.uint8)
+                if self.rank == 0:
+                    uid = torch.frombuffer(bytearray(_hip.comm_unique_id()), dtype=torch.uint8).clone()
+                if self.backend == "nccl":
+                    uid = uid.cuda(self.device_index)
+                dist.broadcast(uid, src=0, group=group)
+                uid_bytes = bytes(uid.cpu().numpy().tobytes())
+            else:
+                uid_bytes = _hip.comm_unique_id()
+            self.comm = _hip.Comm(self.world, self.rank, uid_bytes, ctx=self.ctx)
         # split (interior / boundary) launches need the tiled kernel and full tile rows: decided at the first sweep
         self._split = None if (engine is None and self.comm_stream is not None and not self._host_staged) else False
         self._views = {}
@@ -110,6 +134,9 @@ class SlabLattice:
 
     def _exchange_device(self):
         """Ghost refresh with device buffers (RCCL send/recv, or a local copy when this rank is its own neighbour)."""
+        if self.comm is not None:  # the library's own RCCL group on the context's stream
+            self.comm.halo_exchange(self.lat)
+            return
         G, R = self.ghost, self.rows
         top, bot = self._rows_tensor(0, G), self._rows_tensor(R - G, G)
         gtop, gbot = self._rows_tensor(-G, G), self._rows_tensor(R, G)
@@ -203,6 +230,9 @@ class SlabLattice:
         """(sum of spins, sum over bonds) of the WHOLE lattice: local reductions + one all-reduce of two int64."""
         self.exchange()  # the bond to the row below the slab needs a fresh ghost row
         s, b = self.lat.observables()
+        if self.comm is not None:
+            tot = self.comm.allreduce([s, b])
+            return int(tot[0]), int(tot[1])
         if not self.distributed:
             return s, b
         # with a process group the sums always go through the collective (a one-rank RCCL group included: the same code
