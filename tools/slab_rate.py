@@ -6,7 +6,7 @@ from tsu import _hip
 from tsu.distributed import SlabLattice
 torch.cuda.set_device(0)
 for rows, cols, S in [(int(a), int(b), int(c)) for a, b, c in (t.split("x") for t in os.environ.get("SLABS", "4096x4096x64,4096x4096x128,2048x16384x32").split(","))]:
-    lat = SlabLattice(rows, cols, periodic=True, sweeps_per_exchange=S, seed=42)
+    lat = SlabLattice(rows, cols, periodic=True, sweeps_per_exchange=S, seed=42, transport=os.environ.get("TRANSPORT", "torch"))
     lat.randomize()
     lat.set_model(1.0, 0.0, 2.269185, _hip.MODE_PHYSICAL)
     lat.sweep(4 * S)
@@ -16,5 +16,5 @@ for rows, cols, S in [(int(a), int(b), int(c)) for a, b, c in (t.split("x") for 
     lat.sweep(n)
     lat.synchronize()
     dt = time.perf_counter() - t
-    print("slab %5d x %5d, %3d sweeps per exchange: %.3e upd/s (%.2f us/sweep)" % (rows, cols, S, rows * cols * n / dt, dt / n * 1e6), flush=True)
+    print("transport %s: slab %5d x %5d, %3d sweeps per exchange: %.3e upd/s (%.2f us/sweep)" % (os.environ.get("TRANSPORT", "torch (device copy at world size 1)"), rows, cols, S, rows * cols * n / dt, dt / n * 1e6), flush=True)
     del lat

@@ -1053,7 +1053,9 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
                 // the numbering restarts (or another strip layout starts): no element may look like one of the new run
                 // (after the chaining above: an earlier launch of this lattice on another stream has finished with the buffer)
                 if (renumber) TSU_HIP_TRY(ctx, hipMemsetAsync(L->d_xbuf, 0, L->xbuf_cap * sizeof(uint64_t), ctx->stream));
-                TSU_HIP_TRY(ctx, tsu_launch_grid_sync(ctx, (const void*)res_kern, dim3((unsigned)ntiles), dim3((unsigned)tv.threads), &P, lds_bytes, ctx->stream));
+                // (a slab's launches alternate with the halo exchange's RCCL kernels on this stream: ordinary launch, see tsu_launch_grid_sync)
+                TSU_HIP_TRY(ctx, tsu_launch_grid_sync(ctx, (const void*)res_kern, dim3((unsigned)ntiles), dim3((unsigned)tv.threads), &P, lds_bytes, ctx->stream,
+                                                      slab));
                 L->launches += 1;
                 L->cur ^= 1;
                 {

@@ -63,9 +63,12 @@ int tsu_grid_exclusive_end(tsu_ctx* ctx);
 // profiles/r02_exit_crash_symbolised.txt) -- TSU_COOP_LAUNCH=1 forces the cooperative API even then.  Inside a batch of
 // lattices (tsu_ising2d_sweep_batch: several small grids share the chip on side streams, their number bounded by the batch
 // itself) the launches are ordinary: the runtime serialises cooperative launches on one queue (measured: 32 lattices of
-// 512 x 512, 2500 sweeps: 248 ms against 87 ms; profiles/r02_coop_launch_cost.txt).
+// 512 x 512, 2500 sweeps: 248 ms against 87 ms; profiles/r02_coop_launch_cost.txt).  The same holds for slabs whose launches
+// alternate with RCCL kernels on the stream (beside_rccl): a cooperative launch after every halo exchange cost 230 us per
+// exchange (4096 x 4096 slab, 128 sweeps per exchange: 2.0e12 instead of 2.55e12 upd/s), an ordinary one 12.
 bool tsu_use_coop_launch();
-hipError_t tsu_launch_grid_sync(tsu_ctx* ctx, const void* kernel, dim3 grid, dim3 block, void* param_struct, size_t lds_bytes, hipStream_t stream);
+hipError_t tsu_launch_grid_sync(tsu_ctx* ctx, const void* kernel, dim3 grid, dim3 block, void* param_struct, size_t lds_bytes, hipStream_t stream,
+                                bool beside_rccl = false);
 
 extern thread_local char g_tsu_init_err[512];
 

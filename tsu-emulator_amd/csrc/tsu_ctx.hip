@@ -60,9 +60,10 @@ bool tsu_use_coop_launch() {
     return mode == 1;
 }
 
-hipError_t tsu_launch_grid_sync(tsu_ctx* ctx, const void* kernel, dim3 grid, dim3 block, void* param_struct, size_t lds_bytes, hipStream_t stream) {
+hipError_t tsu_launch_grid_sync(tsu_ctx* ctx, const void* kernel, dim3 grid, dim3 block, void* param_struct, size_t lds_bytes, hipStream_t stream,
+                                bool beside_rccl) {
     void* args[] = {param_struct};
-    if (tsu_use_coop_launch() && !ctx->in_batch) {
+    if (tsu_use_coop_launch() && !ctx->in_batch && !beside_rccl) {
         const hipError_t e = hipLaunchCooperativeKernel(kernel, grid, block, args, (unsigned)lds_bytes, stream);
         if (e == hipSuccess) return e;
         // the runtime declined (a device / driver without cooperative launch, or its own residency arithmetic disagrees with the
