@@ -1,4 +1,4 @@
-"""Exit-time crash probe: one dense sweep through hipLaunchCooperativeKernel (TSU_K2_COOP_LAUNCH=1) or the
+"""Exit-time crash probe: one dense sweep through hipLaunchCooperativeKernel (TSU_COOP_LAUNCH=1) or the
 ordinary launch, then /proc/self/maps is written to gpurun_out/ so that the frames glog prints at a crash can be attributed
 to libraries.  usage: coop_exit_probe.py TAG [close|noclose] [n]"""
 import os
