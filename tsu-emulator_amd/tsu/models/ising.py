@@ -101,7 +101,13 @@ class IsingModel:
     def J_sparse(self):
         """The coupling matrix as ``scipy.sparse`` CSR (sparse models: the stored graph; dense models: a conversion)."""
         import scipy.sparse as sp
-        return self._Jsp.tocsr() if self.sparse else sp.csr_matrix(self.J)
+        return self._csr() if self.sparse else sp.csr_matrix(self.J)
+
+    def _csr(self):
+        """CSR form of a sparse model's couplings (converted once after the last set_coupling: energy() runs per sample)."""
+        if getattr(self._Jsp, "format", "") != "csr":
+            self._Jsp = self._Jsp.tocsr()
+        return self._Jsp
 
     def set_coupling(self, i: int, j: int, strength: float):
         """Reference: ising.py:77-86 (symmetric assignment, not accumulation)."""
@@ -125,7 +131,7 @@ class IsingModel:
         """Reference: ising.py:99-117 -- E(s) = -1/2 s'Js - h's."""
         state = np.asarray(state)
         if self.sparse:
-            interaction_energy = -0.5 * state.dot(self._Jsp.tocsr().dot(state))
+            interaction_energy = -0.5 * state.dot(self._csr().dot(state))
         else:
             interaction_energy = -0.5 * state.dot(self.J).dot(state)
         field_energy = -self.h.dot(state)
@@ -142,12 +148,12 @@ class IsingModel:
     def _get_bit_coupling(self) -> np.ndarray:
         """Reference: ising.py:127-138 -- J_bit = 4 J."""
         if self.sparse:
-            return (4 * self._Jsp).tocsr()
+            return (4 * self._csr()).tocsr()
         return 4 * self.J
 
     def _get_bit_bias(self) -> np.ndarray:
         """Reference: ising.py:140-148 (``compat``: verbatim, including its sign), or the corrected conversion."""
-        rowsum = np.asarray(self._Jsp.sum(axis=1)).ravel() if self.sparse else np.sum(self.J, axis=1)
+        rowsum = np.asarray(self._csr().sum(axis=1)).ravel() if self.sparse else np.sum(self.J, axis=1)
         if self.bias_mode == "compat":
             return -2 * self.h + 2 * rowsum
         return 2 * self.h - 2 * rowsum
