@@ -219,7 +219,7 @@ def time_dense(hip, ctx, counters, n=16384):
                                  "(profiles/r02_pmc_k2_pipe_N16384_f32.txt)"}}
 
 
-def time_sparse_chain(hip, ctx, n=1 << 24):
+def time_sparse_chain(hip, ctx, counters, n=1 << 24):
     """K5: colour-parallel sweeps of a 2^24-site open chain (the reference's IsingChain would need a 2 PB dense J)."""
     import scipy.sparse as sp
     from tsu.graph import canonical_csr
@@ -239,8 +239,10 @@ def time_sparse_chain(hip, ctx, n=1 << 24):
     alg = 17 + 13 * 2  # bytes per update: row extent 8 + bias 8 + state write 1, per neighbour column 4 + coupling 8 + bit 1
     gbs = alg * n / (ms * 1e-3) / 1e9
     return {"sites": n, "ms_per_sweep": ms, "spin_updates_per_s": n / (ms * 1e-3),
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                         "note": "algorithmic 17 + 13 deg bytes per update (CSR gather kernel, deg = 2)"},
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "traffic": counters.get("k5_color_chain_2p24", {}).get("hbm_bytes"),
+                         "note": "algorithmic 17 + 13 deg bytes per update (CSR gather kernel, deg = 2) = 361 MB per launch of one colour "
+                                 "class (2^23 sites); traffic: PMC bytes per such launch (upper estimate, see profiles/counters.json)"},
             "M": m / n}
 
 
@@ -476,7 +478,7 @@ def main():
             extra["ising2d_1000x1000"] = time_lattice(hip, ctx, 1000, 0, 4096)
             extra["langevin_dim_2^20"] = time_langevin(hip, ctx, counters)
             extra["dense_gibbs"] = time_dense(hip, ctx, counters)
-            extra["sparse_chain_2^24"] = time_sparse_chain(hip, ctx)
+            extra["sparse_chain_2^24"] = time_sparse_chain(hip, ctx, counters)
             out["extra"] = extra
         print(json.dumps(out))
     if world > 1:
