@@ -166,3 +166,19 @@ def test_config5_langevin_2pow20_matches_oracle_and_stationary_variance(hip):
     x = lc.get_state()
     assert abs(x.var() - 0.505051) < 0.004 and abs(x.mean()) < 0.004
     lc.close()
+
+
+def test_onsager_values_on_8192_squared_nibble_resident_lattice():
+    """Physics at the roofline target's size on the kernel that holds it (512 x 512 nibble-plane tiles resident in LDS, strips
+    exchanged between the 256 tiles): IsingModel2D(8192) at T = 2.0 < T_c from a cold start reproduces Onsager's infinite-lattice
+    magnetisation (1 - sinh(2/T)^-4)^(1/8) = 0.911319 and energy u = -1.745565 per site."""
+    from tsu.models.ising import IsingModel2D
+    m = IsingModel2D(size=8192, temperature=2.0, seed=77, initial="up")
+    m.equilibrate(n_sweeps=3000)
+    ms, es = [], []
+    for _ in range(20):
+        m.gibbs_update(100)
+        ms.append(m.magnetization())
+        es.append(m.energy() / m.n_spins)
+    assert abs(np.mean(ms) - 0.911319) < 0.0005, np.mean(ms)
+    assert abs(np.mean(es) + 1.745565) < 0.0005, np.mean(es)
