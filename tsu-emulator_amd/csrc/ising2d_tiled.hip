@@ -128,6 +128,7 @@ struct Rows2Ctx {
     int tr_lo, npairs;   // first tile row of the half-sweep's range, number of row pairs
     int rgf;             // global row of tile row tr_lo (wrapped)
     int total_rows;
+    int rg_tile0, wrap_tr;  // EDGE tiles: global row of tile row 0 (wrapped); the tile row whose global row is 0 again
     uint32_t hs, tag_hi, tag_lo, k0, k1;
     uint32_t tblH0, tblH1, tblL0, tblL1;
     uint32_t t3H0, t3H1, t3L0, t3L1;  // open lattices: degree 3 / degree 2 byte tables
@@ -191,6 +192,23 @@ static __device__ __forceinline__ uint64_t pack_flags(const u32x4& d) {
     return (uint64_t)nlo | ((uint64_t)nhi << 32);
 }
 
+// EDGE tiles: global rows of the pair at tile rows (tr, tr + 1).  The lattice's last row falls at ONE tile row (wrap_tr), so a
+// wave's lanes (a few consecutive row lanes: tile rows tr_wave .. tr_wave + SPAN) lie on one side of it in all but one
+// wave-iteration per half-sweep: the offset is a scalar select and the per-lane compares run in that one iteration only
+// (they cost the edge tiles +4.7 % when every lane made them every time -- and the edge tiles set every tile's pace).
+template <int NO>
+static __device__ __forceinline__ void edge_rows(const Rows2Ctx& c, int tr_wave, int tr, int& rga, int& rgb) {
+    constexpr int SPAN = 2 * ((NO - 1 + 63) / NO) + 1;  // tile rows below the first lane's that a wave's 64 lanes can reach
+    const int s_off = tr_wave >= c.wrap_tr ? c.rg_tile0 - c.total_rows : c.rg_tile0;
+    rga = tr + s_off;
+    rgb = rga + 1;
+    if (__builtin_expect(tr_wave < c.wrap_tr && tr_wave + SPAN >= c.wrap_tr, 0)) {  // wave-uniform
+        asm volatile("" : "+v"(rga), "+v"(rgb));  // a real branch: as selects this would cost every iteration 9 instructions
+        if (rga >= c.total_rows) rga -= c.total_rows;
+        if (rgb >= c.total_rows) rgb -= c.total_rows;
+    }
+}
+
 // P0 = column parity of the updated colour in row tr_lo (and 1-P0 in the row below it)
 template <int NO, int P0, bool EDGE, bool OPEN, bool SEAM = false>
 static __device__ __forceinline__ void sweep_pairs(const Rows2Ctx& c, const PhiloxKeys& K, int al, int oct, uint32_t cq, int RL) {
@@ -201,9 +219,11 @@ static __device__ __forceinline__ void sweep_pairs(const Rows2Ctx& c, const Phil
     const int off_end = (c.tr_lo + 2 * c.npairs) * NO * 8;
     const int off_step = 2 * RL * NO * 8;
     int off = ((c.tr_lo + 2 * al) * NO + oct) * 8;
-    int rg = c.rgf + 2 * al;
+    // EDGE (the tile's window crosses the lattice's last row): rg counts tile rows and the wrap is applied per wave, see below
+    int rg = (EDGE ? c.tr_lo : c.rgf) + 2 * al;
+    int tr_wave = EDGE ? __builtin_amdgcn_readfirstlane(rg) : 0;  // tile row of the wave's first lane (lanes ascend in al)
 #pragma unroll 1
-    for (; off < off_end; off += off_step, rg += 2 * RL) {
+    for (; off < off_end; off += off_step, rg += 2 * RL, tr_wave += 2 * RL) {
         asm volatile("" : "+v"(off), "+v"(rg));
         // issue the six LDS reads, run the two Philox blocks (which do not depend on them) while they are in flight,
         // and only then consume the neighbour rows
@@ -220,10 +240,7 @@ static __device__ __forceinline__ void sweep_pairs(const Rows2Ctx& c, const Phil
         const uint64_t Nb = SEAM ? *reinterpret_cast<const uint64_t*>(ps + NO * 8 + (P0 ? -8 : 8)) : 0ull;
         __builtin_amdgcn_sched_barrier(0);  // the reads stay above the Philox blocks ...
         int rga = rg, rgb = rg + 1;
-        if (EDGE) {
-            if (rga >= c.total_rows) rga -= c.total_rows;
-            if (rgb >= c.total_rows) rgb -= c.total_rows;
-        }
+        if (EDGE) edge_rows<NO>(c, tr_wave, rg, rga, rgb);
         const u32x4 w0 = philox_vk(cq, (uint32_t)rga, c.hs, c.tag_hi, K);
         const u32x4 w1 = philox_vk(cq, (uint32_t)rgb, c.hs, c.tag_hi, K);
         __builtin_amdgcn_sched_barrier(0);  // ... and their first use stays below
@@ -310,9 +327,10 @@ static __device__ __forceinline__ void sweep_pairs_nib(const Rows2Ctx& c, const 
     const int off_end = (c.tr_lo + 2 * c.npairs) * NO * 4;
     const int off_step = 2 * RL * NO * 4;
     int off = ((c.tr_lo + 2 * al) * NO + oct) * 4;
-    int rg = c.rgf + 2 * al;
+    int rg = (EDGE ? c.tr_lo : c.rgf) + 2 * al;
+    int tr_wave = EDGE ? __builtin_amdgcn_readfirstlane(rg) : 0;
 #pragma unroll 1
-    for (; off < off_end; off += off_step, rg += 2 * RL) {
+    for (; off < off_end; off += off_step, rg += 2 * RL, tr_wave += 2 * RL) {
         asm volatile("" : "+v"(off), "+v"(rg));
         const char* ps = ps0 + off;
         const uint32_t R0 = *reinterpret_cast<const uint32_t*>(ps - NO * 4), R1 = *reinterpret_cast<const uint32_t*>(ps);
@@ -321,10 +339,7 @@ static __device__ __forceinline__ void sweep_pairs_nib(const Rows2Ctx& c, const 
         const uint32_t A1 = *reinterpret_cast<const uint32_t*>(ps + NO * 4 + (P0 ? -4 : 4));  // row b: the other side
         __builtin_amdgcn_sched_barrier(0);
         int rga = rg, rgb = rg + 1;
-        if (EDGE) {
-            if (rga >= c.total_rows) rga -= c.total_rows;
-            if (rgb >= c.total_rows) rgb -= c.total_rows;
-        }
+        if (EDGE) edge_rows<NO>(c, tr_wave, rg, rga, rgb);
         const u32x4 w0 = philox_vk(cq, (uint32_t)rga, c.hs, c.tag_hi, K);
         const u32x4 w1 = philox_vk(cq, (uint32_t)rgb, c.hs, c.tag_hi, K);
         __builtin_amdgcn_sched_barrier(0);
@@ -369,7 +384,7 @@ struct ResidentParams {
                      // live on the slab's deep ghost rows (the region that is still exact shrinks, as between exchanges),
                      // and for an open lattice: beyond the edge there is nothing, and nothing stays there
     int wrap_x;      // tile columns wrap (periodic); 0 for an open lattice
-    long long* dbg;  // TSU_K1_VERBOSE=2: wall_clock64 ticks of tile 0 spent in [sweeps, publish, wait, fetch]
+    long long* dbg;  // TSU_K1_VERBOSE=2: per tile, wall_clock64 ticks spent in [sweeps, publish, wait, fetch]
 };
 
 template <int HT, int WO, int THREADS, bool OPEN = false, bool RESIDENT = false, bool NIB = false>
@@ -471,6 +486,8 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
     Rows2Ctx c;
     c.s_thr = s_thr;
     c.total_rows = (int)p.total_rows;
+    c.rg_tile0 = (int)rg0;
+    c.wrap_tr = (int)(p.total_rows - rg0);
     c.tag_hi = p.tag_hi; c.tag_lo = p.tag_lo; c.k0 = p.k0; c.k1 = p.k1;
     // the threshold byte tables live in VGPRs: v_perm_b32 may read only one SGPR, so SGPR tables cost a v_mov per use
     c.tblH0 = p.tblH0; c.tblH1 = p.tblH1; c.tblL0 = p.tblL0; c.tblL1 = p.tblL1;
@@ -500,7 +517,7 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
 
     const int n_gen = RESIDENT ? R->n_gen : 1;
     long long tl0 = 0, tl[4] = {0, 0, 0, 0};
-    const bool timing = RESIDENT && R->dbg && blockIdx.x == 0 && tid == 0;
+    const bool timing = RESIDENT && R->dbg && tid == 0;
     if (timing) tl0 = wall_clock64();
 #define RES_MARK(q)                         \
     if (timing) {                           \
@@ -677,7 +694,7 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
     }
     }  // generations
     if (timing)
-        for (int q = 0; q < 4; ++q) R->dbg[q] = tl[q];
+        for (int q = 0; q < 4; ++q) R->dbg[4 * blockIdx.x + q] = tl[q];
 #undef RES_MARK
     // interior octets are tile columns 1 .. NO-2: the same thread -> column mapping, halo columns idle
     if (al < RLMAX && oct >= 1 && oct <= WO && q0 + oct - 1 < p.nchunks + p.q_shift) {
@@ -1040,7 +1057,7 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
                 P.r.dbg = nullptr;
                 long long* d_dbg = nullptr;
                 if (vb && atoi(vb) >= 2) {
-                    TSU_HIP_TRY(ctx, hipMalloc(&d_dbg, 4 * sizeof(long long)));
+                    TSU_HIP_TRY(ctx, hipMalloc(&d_dbg, (size_t)4 * ntiles * sizeof(long long)));
                     P.r.dbg = d_dbg;
                 }
                 if (vb)
@@ -1063,11 +1080,40 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
                     if (rcx != TSU_OK) return rcx;
                 }
                 if (d_dbg) {
-                    long long h[4];
-                    (void)hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost);
+                    std::vector<long long> h((size_t)4 * ntiles);
+                    (void)hipMemcpy(h.data(), d_dbg, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
                     (void)hipFree(d_dbg);
-                    fprintf(stderr, "[tsu]   tile 0, us per generation: sweeps %.1f, publish %.1f, wait %.1f, fetch %.1f\n",
-                            h[0] / 100.0 / P.r.n_gen, h[1] / 100.0 / P.r.n_gen, h[2] / 100.0 / P.r.n_gen, h[3] / 100.0 / P.r.n_gen);
+                    static const char* const what[4] = {"sweeps", "publish", "wait", "fetch"};
+                    fprintf(stderr, "[tsu]   us per generation over %d tiles (mean / min / max):", ntiles);
+                    for (int q = 0; q < 4; ++q) {
+                        double sum = 0, lo = 1e30, hi = 0;
+                        for (int t = 0; t < ntiles; ++t) {
+                            const double v = h[(size_t)4 * t + q] / 100.0 / P.r.n_gen;
+                            sum += v;
+                            lo = v < lo ? v : lo;
+                            hi = v > hi ? v : hi;
+                        }
+                        fprintf(stderr, " %s %.1f / %.1f / %.1f%s", what[q], sum / ntiles, lo, hi, q < 3 ? "," : "\n");
+                    }
+                    if (atoi(vb) >= 3) {  // by XCD (workgroup index mod 8): does one die run behind the others?
+                        for (int x = 0; x < 8; ++x) {
+                            double sw = 0, wt = 0;
+                            int cnt = 0;
+                            for (int t = x; t < ntiles; t += 8, ++cnt) {
+                                sw += h[(size_t)4 * t] / 100.0 / P.r.n_gen;
+                                wt += h[(size_t)4 * t + 2] / 100.0 / P.r.n_gen;
+                            }
+                            if (cnt) fprintf(stderr, "[tsu]   xcd %d: sweeps %.2f wait %.2f\n", x, sw / cnt, wt / cnt);
+                        }
+                        if (atoi(vb) >= 4)  // the whole map: sweeps / wait per tile, one line per tile row
+                            for (int y = 0; y < tiles_y; ++y) {
+                                fprintf(stderr, "[tsu]   row %3d:", y);
+                                for (int x = 0; x < p.tiles_x; ++x)
+                                    fprintf(stderr, " %.1f/%.1f", h[(size_t)4 * (y * p.tiles_x + x)] / 100.0 / P.r.n_gen,
+                                            h[(size_t)4 * (y * p.tiles_x + x) + 2] / 100.0 / P.r.n_gen);
+                                fprintf(stderr, "\n");
+                            }
+                    }
                 }
                 done += chunk;
             }
