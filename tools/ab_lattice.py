@@ -1,6 +1,6 @@
 """A/B timing of lattice sweeps between builds of the library on ONE box (boxes differ by several per cent, so numbers from
 different gpurun calls do not compare).  Each build runs in its own child process (TSU_HIP_LIB), alternating, several rounds.
-usage: python tools/ab_lattice.py libA.so libB.so [L ...]      child: python tools/ab_lattice.py --child L [L ...]"""
+usage: python tools/ab_lattice.py libA.so,libB.so[,libC.so ...] [L ...]      child: python tools/ab_lattice.py --child L [L ...]"""
 import os
 import subprocess
 import sys
@@ -36,8 +36,8 @@ if __name__ == "__main__":
     if sys.argv[1] == "--child":
         child([int(a) for a in sys.argv[2:]])
     else:
-        libs = sys.argv[1:3]
-        sizes = sys.argv[3:] or ["4096", "8192"]
+        libs = sys.argv[1].split(",")
+        sizes = sys.argv[2:] or ["4096", "8192"]
         for rnd in range(3):
             for lib in libs:
                 env = dict(os.environ, TSU_HIP_LIB=os.path.abspath(lib))

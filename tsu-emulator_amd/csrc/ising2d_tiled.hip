@@ -203,7 +203,9 @@ static __device__ __forceinline__ void edge_rows(const Rows2Ctx& c, int tr_wave,
     rga = tr + s_off;
     rgb = rga + 1;
     if (__builtin_expect(tr_wave < c.wrap_tr && tr_wave + SPAN >= c.wrap_tr, 0)) {  // wave-uniform
-        asm volatile("" : "+v"(rga), "+v"(rgb));  // a real branch: as selects this would cost every iteration 9 instructions
+        rga = tr + c.rg_tile0;
+        asm volatile("" : "+v"(rga));  // a real branch: as selects this would cost every iteration 9 instructions
+        rgb = rga + 1;
         if (rga >= c.total_rows) rga -= c.total_rows;
         if (rgb >= c.total_rows) rgb -= c.total_rows;
     }
@@ -211,19 +213,21 @@ static __device__ __forceinline__ void edge_rows(const Rows2Ctx& c, int tr_wave,
 
 // P0 = column parity of the updated colour in row tr_lo (and 1-P0 in the row below it)
 template <int NO, int P0, bool EDGE, bool OPEN, bool SEAM = false>
-static __device__ __forceinline__ void sweep_pairs(const Rows2Ctx& c, const PhiloxKeys& K, int al, int oct, uint32_t cq, int RL) {
+static __device__ __forceinline__ void sweep_pairs(const Rows2Ctx& c, const PhiloxKeys& K, int tr_first, int tr_end, int step_rows, int oct,
+                                                   uint32_t cq) {
     // One byte offset into the source plane and one row counter are the only induction variables (kept opaque so
     // that the compiler does not re-derive them from a separate trip counter); everything else is an immediate.
     const char* const ps0 = reinterpret_cast<const char*>(c.Ps);
     const int d_off = (int)(reinterpret_cast<const char*>(c.Pd) - ps0);
-    const int off_end = (c.tr_lo + 2 * c.npairs) * NO * 8;
-    const int off_step = 2 * RL * NO * 8;
-    int off = ((c.tr_lo + 2 * al) * NO + oct) * 8;
-    // EDGE (the tile's window crosses the lattice's last row): rg counts tile rows and the wrap is applied per wave, see below
-    int rg = (EDGE ? c.tr_lo : c.rgf) + 2 * al;
-    int tr_wave = EDGE ? __builtin_amdgcn_readfirstlane(rg) : 0;  // tile row of the wave's first lane (lanes ascend in al)
+    // this thread: the pairs at tile rows tr_first, tr_first + step_rows, ... < tr_end (tr_first has the parity of c.tr_lo)
+    const int off_end = tr_end * NO * 8;
+    const int off_step = step_rows * NO * 8;
+    int off = (tr_first * NO + oct) * 8;
+    // EDGE (the tile's window crosses the lattice's last row): rg counts tile rows and the wrap is applied per wave, see edge_rows
+    int rg = EDGE ? tr_first : c.rgf + (tr_first - c.tr_lo);
+    int tr_wave = EDGE ? __builtin_amdgcn_readfirstlane(rg) : 0;  // tile row of the wave's first lane (lanes ascend in rows)
 #pragma unroll 1
-    for (; off < off_end; off += off_step, rg += 2 * RL, tr_wave += 2 * RL) {
+    for (; off < off_end; off += off_step, rg += step_rows, tr_wave += step_rows) {
         asm volatile("" : "+v"(off), "+v"(rg));
         // issue the six LDS reads, run the two Philox blocks (which do not depend on them) while they are in flight,
         // and only then consume the neighbour rows
@@ -321,16 +325,17 @@ static __device__ __forceinline__ uint32_t nib_pack(const u32x4& d) {
 }
 
 template <int NO, int P0, bool EDGE>
-static __device__ __forceinline__ void sweep_pairs_nib(const Rows2Ctx& c, const PhiloxKeys& K, int al, int oct, uint32_t cq, int RL) {
+static __device__ __forceinline__ void sweep_pairs_nib(const Rows2Ctx& c, const PhiloxKeys& K, int tr_first, int tr_end, int step_rows, int oct,
+                                                       uint32_t cq) {
     const char* const ps0 = reinterpret_cast<const char*>(c.Ps);
     const int d_off = (int)(reinterpret_cast<const char*>(c.Pd) - ps0);
-    const int off_end = (c.tr_lo + 2 * c.npairs) * NO * 4;
-    const int off_step = 2 * RL * NO * 4;
-    int off = ((c.tr_lo + 2 * al) * NO + oct) * 4;
-    int rg = (EDGE ? c.tr_lo : c.rgf) + 2 * al;
+    const int off_end = tr_end * NO * 4;
+    const int off_step = step_rows * NO * 4;
+    int off = (tr_first * NO + oct) * 4;
+    int rg = EDGE ? tr_first : c.rgf + (tr_first - c.tr_lo);
     int tr_wave = EDGE ? __builtin_amdgcn_readfirstlane(rg) : 0;
 #pragma unroll 1
-    for (; off < off_end; off += off_step, rg += 2 * RL, tr_wave += 2 * RL) {
+    for (; off < off_end; off += off_step, rg += step_rows, tr_wave += step_rows) {
         asm volatile("" : "+v"(off), "+v"(rg));
         const char* ps = ps0 + off;
         const uint32_t R0 = *reinterpret_cast<const uint32_t*>(ps - NO * 4), R1 = *reinterpret_cast<const uint32_t*>(ps);
@@ -529,77 +534,46 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
     // as "octet -1" padding): a static __shared__ word would push a 160 KB workgroup past the CU's LDS
     volatile int& s_fail = *reinterpret_cast<volatile int*>(lds);
     if (RESIDENT && tid == 0) s_fail = 0;
-    for (int gen = 0; gen < n_gen; ++gen) {
-    const int kg = (RESIDENT && gen == n_gen - 1) ? R->k_last : k;  // sweeps of this generation (the tile keeps TR = H + 4k)
-    const uint32_t sweep_g = sweep0 + (uint32_t)(gen * k);
-    for (int hsi = 0; hsi < 2 * kg; ++hsi) {
-        __syncthreads();
-        const int kappa = hsi & 1;
-        c.hs = 2u * (sweep_g + (uint32_t)(hsi >> 1)) + (uint32_t)kappa;
-        c.Pd = kappa ? plane1 : plane0;
-        c.Ps = kappa ? plane0 : plane1;
-        c.tr_lo = 1 + hsi;
-        c.npairs = (TR - 2 - 2 * hsi) / 2;  // rows [1 + hsi, TR - 2 - hsi] in pairs (TR is even)
-        int rgf = (int)rg0 + c.tr_lo;
-        if (!OPEN && rgf >= c.total_rows) rgf -= c.total_rows;
-        c.rgf = rgf;
-        const int par0 = (int)((p.row0 + Rb + c.tr_lo + kappa) & 1);
-        if (al < RL) {
-            if (NIB) {
-                if (edge) {
-                    if (par0) sweep_pairs_nib<NO, 1, true>(c, K, al, oct, cq, RL);
-                    else sweep_pairs_nib<NO, 0, true>(c, K, al, oct, cq, RL);
-                } else {
-                    if (par0) sweep_pairs_nib<NO, 1, false>(c, K, al, oct, cq, RL);
-                    else sweep_pairs_nib<NO, 0, false>(c, K, al, oct, cq, RL);
-                }
-            } else if (OPEN) {
-                if (par0) sweep_pairs<NO, 1, false, true>(c, K, al, oct, cq, RL);
-                else sweep_pairs<NO, 0, false, true>(c, K, al, oct, cq, RL);
-            } else if (seam) {
-                if (par0) sweep_pairs<NO, 1, true, false, true>(c, K, al, oct, cq, RL);
-                else sweep_pairs<NO, 0, true, false, true>(c, K, al, oct, cq, RL);
-            } else if (edge) {
-                if (par0) sweep_pairs<NO, 1, true, false>(c, K, al, oct, cq, RL);
-                else sweep_pairs<NO, 0, true, false>(c, K, al, oct, cq, RL);
-            } else {
-                if (par0) sweep_pairs<NO, 1, false, false>(c, K, al, oct, cq, RL);
-                else sweep_pairs<NO, 0, false, false>(c, K, al, oct, cq, RL);
-            }
-        }
-    }
-    __syncthreads();
-    RES_MARK(0);
-    if (RESIDENT && gen + 1 < n_gen) {
-        // ---- publish this generation's boundary strips, then refresh the halo from the neighbours' strips
-        const int tiles_x = p.tiles_x, tiles_y = R->tiles_y, ntiles = tiles_x * tiles_y;
-        const int me = ty * tiles_x + tx;
-        const int n_tb = 2 * k * WO, n_lr = H;                  // elements per plane of a top/bottom and a left/right strip
-        const int xstride = 4 * n_tb + 4 * n_lr;                 // TOP[2][n_tb] BOTTOM[2][n_tb] LEFT[2][n_lr] RIGHT[2][n_lr]
-        uint64_t* mine = R->xbuf + ((size_t)(gen & 1) * ntiles + me) * xstride;
-        // Every strip element (8 up-flags, one per byte) carries the 14-bit number of its generation in the spare bits 1..7
-        // of its bytes 0 and 1, so a reader validates each element by itself: no "strips complete" flag, no wait for the
-        // stores to be acknowledged before raising one, no wait for the flag before fetching -- the refresh is a single
-        // round trip that is repeated only for the elements that were not there yet.  (A slot is rewritten every second
-        // generation and neighbours are never more than one generation apart, so a stale element always carries another
-        // number; the host clears the buffer when the numbering restarts or the strip layout changes.)
-        // (nibble planes: an element is the octet's dword, the number sits above it in bits 32..45)
+
+    // ---- the strip exchange between generations (RESIDENT).  Only colour plane 1 travels: a generation starts with the
+    // half-sweep of colour 0, which rewrites every colour-0 site of the tile (halo included) from colour 1 alone.
+    // Layout of a tile's slot: TOP[n_tb] BOTTOM[n_tb] LEFT[n_lr] RIGHT[n_lr].
+    // Every strip element (8 up-flags, one per byte) carries the 14-bit number of its generation in the spare bits 1..7
+    // of its bytes 0 and 1, so a reader validates each element by itself: no "strips complete" flag, no wait for the
+    // stores to be acknowledged before raising one, no wait for the flag before fetching -- the refresh is a single
+    // round trip that is repeated only for the elements that were not there yet.  (A slot is rewritten every second
+    // generation and neighbours are never more than one generation apart, so a stale element always carries another
+    // number; the host clears the buffer when the numbering restarts or the strip layout changes.)
+    // (nibble planes: an element is the octet's dword, the number sits above it in bits 32..45)
+    const int n_tb = 2 * k * WO, n_lr = H;  // elements of a top/bottom and of a left/right strip
+    const int xstride = 2 * n_tb + 2 * n_lr;
+    constexpr uint64_t TAG_MASK = NIB ? 0xFFFFFFFF00000000ull : 0xFEFEull, FLAG_MASK = NIB ? 0x11111111ull : 0x0101010101010101ull;
+    auto strip_tag = [&](int gen) -> uint64_t {
         const uint32_t G = R->gen0 + (uint32_t)gen;
-        const uint64_t tag = NIB ? ((uint64_t)G << 32) : (((uint64_t)(G & 0x7Fu) << 1) | ((uint64_t)((G >> 7) & 0x7Fu) << 9));
-        constexpr uint64_t TAG_MASK = NIB ? 0xFFFFFFFF00000000ull : 0xFEFEull, FLAG_MASK = NIB ? 0x11111111ull : 0x0101010101010101ull;
-        for (int i = tid; i < 2 * n_tb; i += THREADS) {
-            const int pl = i / n_tb, rem = i - pl * n_tb, r = rem / WO, o = rem - r * WO;
-            const E* P = pl ? plane1 : plane0;
-            xst(mine + i, (uint64_t)P[(2 * k + r) * NO + 1 + o] | tag);           // TOP: first 2k interior rows
-            xst(mine + 2 * n_tb + i, (uint64_t)P[(H + r) * NO + 1 + o] | tag);    // BOTTOM: last 2k interior rows
+        return NIB ? ((uint64_t)G << 32) : (((uint64_t)(G & 0x7Fu) << 1) | ((uint64_t)((G >> 7) & 0x7Fu) << 9));
+    };
+    // publish generation gen's boundary strips: its first / last 2k interior rows and first / last interior octet column
+    auto publish = [&](int gen) {
+        RES_MARK(0);
+        const int ntiles = p.tiles_x * R->tiles_y, me = ty * p.tiles_x + tx;
+        uint64_t* mine = R->xbuf + ((size_t)(gen & 1) * ntiles + me) * xstride;
+        const uint64_t tag = strip_tag(gen);
+        for (int i = tid; i < n_tb; i += THREADS) {
+            const int r = i / WO, o = i - r * WO;
+            xst(mine + i, (uint64_t)plane1[(2 * k + r) * NO + 1 + o] | tag);     // TOP: first 2k interior rows
+            xst(mine + n_tb + i, (uint64_t)plane1[(H + r) * NO + 1 + o] | tag);  // BOTTOM: last 2k interior rows
         }
-        for (int i = tid; i < 2 * n_lr; i += THREADS) {
-            const int pl = i / n_lr, r = i - pl * n_lr;
-            const E* P = pl ? plane1 : plane0;
-            xst(mine + 4 * n_tb + i, (uint64_t)P[(2 * k + r) * NO + 1] | tag);             // LEFT: first interior octet
-            xst(mine + 4 * n_tb + 2 * n_lr + i, (uint64_t)P[(2 * k + r) * NO + WO] | tag); // RIGHT: last interior octet
+        for (int i = tid; i < n_lr; i += THREADS) {
+            xst(mine + 2 * n_tb + i, (uint64_t)plane1[(2 * k + i) * NO + 1] | tag);          // LEFT: first interior octet
+            xst(mine + 2 * n_tb + n_lr + i, (uint64_t)plane1[(2 * k + i) * NO + WO] | tag);  // RIGHT: last interior octet
         }
         RES_MARK(1);
+    };
+    // refresh the halo of colour plane 1 from the eight neighbours' strips of generation gen
+    auto fetch = [&](int gen) {
+        RES_MARK(0);
+        const int tiles_x = p.tiles_x, tiles_y = R->tiles_y, ntiles = tiles_x * tiles_y;
+        const uint64_t tag = strip_tag(gen);
         const int txl = tx == 0 ? tiles_x - 1 : tx - 1, txr = tx == tiles_x - 1 ? 0 : tx + 1;
         const int tyu = ty == 0 ? tiles_y - 1 : ty - 1, tyd = ty == tiles_y - 1 ? 0 : ty + 1;
         const bool has_u = R->wrap_y || ty > 0, has_d = R->wrap_y || ty < tiles_y - 1;
@@ -617,33 +591,33 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
         // interior rows: octet 0 from the left neighbour's RIGHT strip, octet NO-1 from the right one's LEFT.  Every load of
         // a thread is issued before the first is looked at, and unconditionally: a neighbour index always names a real
         // tile, a missing neighbour's value is neither checked nor stored.
-        constexpr int FI = (2 * 2 * 8 * NO + THREADS - 1) / THREADS;   // k <= 8
+        constexpr int FI = (2 * 8 * NO + THREADS - 1) / THREADS;   // k <= 8
         constexpr int TH_MAX = 160 * 1024 / (int)sizeof(E) / (2 * NO) - 32;  // tallest (stretched slab) tile whose planes fit the CU's LDS
-        constexpr int SI = (2 * TH_MAX + THREADS - 1) / THREADS;
+        constexpr int SI = (TH_MAX + THREADS - 1) / THREADS;
         const uint64_t* au[FI];
         const uint64_t* ad[FI];
         uint64_t vu[FI], vd[FI], vl[SI], vr[SI];
         bool nu[FI], nd[FI], nl[SI], nr[SI];  // this thread needs the element
 #pragma unroll
         for (int it = 0; it < FI; ++it) {
-            const int i = tid + it * THREADS, ic = i < 2 * 2 * k * NO ? i : 0;
-            const int pl = ic / (2 * k * NO), rem = ic - pl * (2 * k * NO), r = rem / NO, o = rem - r * NO;
-            const int e = pl * n_tb + r * WO;
-            au[it] = o == 0 ? X_ul + 2 * n_tb + e + WO - 1 : (o == NO - 1 ? X_ur + 2 * n_tb + e : X_u + 2 * n_tb + e + o - 1);
+            const int i = tid + it * THREADS, ic = i < 2 * k * NO ? i : 0;
+            const int r = ic / NO, o = ic - r * NO;
+            const int e = r * WO;
+            au[it] = o == 0 ? X_ul + n_tb + e + WO - 1 : (o == NO - 1 ? X_ur + n_tb + e : X_u + n_tb + e + o - 1);
             ad[it] = o == 0 ? X_dl + e + WO - 1 : (o == NO - 1 ? X_dr + e : X_d + e + o - 1);
             const bool col_ok = o == 0 ? has_l : (o == NO - 1 ? has_r : true);
-            nu[it] = i < 2 * 2 * k * NO && has_u && col_ok;
-            nd[it] = i < 2 * 2 * k * NO && has_d && col_ok;
+            nu[it] = i < 2 * k * NO && has_u && col_ok;
+            nd[it] = i < 2 * k * NO && has_d && col_ok;
             vu[it] = xld(au[it]);
             vd[it] = xld(ad[it]);
         }
 #pragma unroll
         for (int it = 0; it < SI; ++it) {
-            const int i = tid + it * THREADS, ic = i < 2 * n_lr ? i : 0;
-            nl[it] = i < 2 * n_lr && has_l;
-            nr[it] = i < 2 * n_lr && has_r;
-            vl[it] = xld(X_l + 4 * n_tb + 2 * n_lr + ic);
-            vr[it] = xld(X_r + 4 * n_tb + ic);
+            const int i = tid + it * THREADS, ic = i < n_lr ? i : 0;
+            nl[it] = i < n_lr && has_l;
+            nr[it] = i < n_lr && has_r;
+            vl[it] = xld(X_l + 2 * n_tb + n_lr + ic);
+            vr[it] = xld(X_r + 2 * n_tb + ic);
         }
         // elements that are not of this generation yet: ask again (a neighbour that finished later; rare and short)
         for (int spins = 0;; ++spins) {
@@ -655,9 +629,9 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
             }
 #pragma unroll
             for (int it = 0; it < SI; ++it) {
-                const int i = tid + it * THREADS, ic = i < 2 * n_lr ? i : 0;
-                if (nl[it] && (vl[it] & TAG_MASK) != tag) { vl[it] = xld(X_l + 4 * n_tb + 2 * n_lr + ic); fresh = false; }
-                if (nr[it] && (vr[it] & TAG_MASK) != tag) { vr[it] = xld(X_r + 4 * n_tb + ic); fresh = false; }
+                const int i = tid + it * THREADS, ic = i < n_lr ? i : 0;
+                if (nl[it] && (vl[it] & TAG_MASK) != tag) { vl[it] = xld(X_l + 2 * n_tb + n_lr + ic); fresh = false; }
+                if (nr[it] && (vr[it] & TAG_MASK) != tag) { vr[it] = xld(X_r + 2 * n_tb + ic); fresh = false; }
             }
             if (fresh) break;
             // the error flag lives in host memory (a PCIe round trip): look at it rarely
@@ -671,27 +645,77 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
 #pragma unroll
         for (int it = 0; it < FI; ++it) {
             const int i = tid + it * THREADS;
-            if (i < 2 * 2 * k * NO) {
-                const int pl = i / (2 * k * NO), rem = i - pl * (2 * k * NO), r = rem / NO, o = rem - r * NO;
-                E* P = pl ? plane1 : plane0;
-                if (nu[it]) P[r * NO + o] = (E)(vu[it] & FLAG_MASK);
-                if (nd[it]) P[(2 * k + H + r) * NO + o] = (E)(vd[it] & FLAG_MASK);
+            if (i < 2 * k * NO) {
+                const int r = i / NO, o = i - r * NO;
+                if (nu[it]) plane1[r * NO + o] = (E)(vu[it] & FLAG_MASK);
+                if (nd[it]) plane1[(2 * k + H + r) * NO + o] = (E)(vd[it] & FLAG_MASK);
             }
         }
 #pragma unroll
         for (int it = 0; it < SI; ++it) {
             const int i = tid + it * THREADS;
-            if (i < 2 * n_lr) {
-                const int pl = i / n_lr, r = i - pl * n_lr;
-                E* P = pl ? plane1 : plane0;
-                if (nl[it]) P[(2 * k + r) * NO] = (E)(vl[it] & FLAG_MASK);
-                if (nr[it]) P[(2 * k + r) * NO + NO - 1] = (E)(vr[it] & FLAG_MASK);
+            if (i < n_lr) {
+                if (nl[it]) plane1[(2 * k + i) * NO] = (E)(vl[it] & FLAG_MASK);
+                if (nr[it]) plane1[(2 * k + i) * NO + NO - 1] = (E)(vr[it] & FLAG_MASK);
             }
         }
+        RES_MARK(3);
+    };
+
+    // one call site for every form of the pair loop: rows tr_first, tr_first + step, ... < tr_end of octet column oc
+    auto run = [&](int par0, int tr_first, int tr_end, int step, int oc, uint32_t cqq) {
+        if (NIB) {
+            if (edge) {
+                if (par0) sweep_pairs_nib<NO, 1, true>(c, K, tr_first, tr_end, step, oc, cqq);
+                else sweep_pairs_nib<NO, 0, true>(c, K, tr_first, tr_end, step, oc, cqq);
+            } else {
+                if (par0) sweep_pairs_nib<NO, 1, false>(c, K, tr_first, tr_end, step, oc, cqq);
+                else sweep_pairs_nib<NO, 0, false>(c, K, tr_first, tr_end, step, oc, cqq);
+            }
+        } else if (OPEN) {
+            if (par0) sweep_pairs<NO, 1, false, true>(c, K, tr_first, tr_end, step, oc, cqq);
+            else sweep_pairs<NO, 0, false, true>(c, K, tr_first, tr_end, step, oc, cqq);
+        } else if (seam) {
+            if (par0) sweep_pairs<NO, 1, true, false, true>(c, K, tr_first, tr_end, step, oc, cqq);
+            else sweep_pairs<NO, 0, true, false, true>(c, K, tr_first, tr_end, step, oc, cqq);
+        } else if (edge) {
+            if (par0) sweep_pairs<NO, 1, true, false>(c, K, tr_first, tr_end, step, oc, cqq);
+            else sweep_pairs<NO, 0, true, false>(c, K, tr_first, tr_end, step, oc, cqq);
+        } else {
+            if (par0) sweep_pairs<NO, 1, false, false>(c, K, tr_first, tr_end, step, oc, cqq);
+            else sweep_pairs<NO, 0, false, false>(c, K, tr_first, tr_end, step, oc, cqq);
+        }
+    };
+    int par0 = 0;
+    auto set_half_sweep = [&](uint32_t sweep_g, int hsi) {
+        const int kappa = hsi & 1;
+        c.hs = 2u * (sweep_g + (uint32_t)(hsi >> 1)) + (uint32_t)kappa;
+        c.Pd = kappa ? plane1 : plane0;
+        c.Ps = kappa ? plane0 : plane1;
+        c.tr_lo = 1 + hsi;
+        c.npairs = (TR - 2 - 2 * hsi) / 2;  // rows [1 + hsi, TR - 2 - hsi] in pairs (TR is even)
+        int rgf = (int)rg0 + c.tr_lo;
+        if (!OPEN && rgf >= c.total_rows) rgf -= c.total_rows;
+        c.rgf = rgf;
+        par0 = (int)((p.row0 + Rb + c.tr_lo + kappa) & 1);
+    };
+    for (int gen = 0; gen < n_gen; ++gen) {
+    const int kg = (RESIDENT && gen == n_gen - 1) ? R->k_last : k;  // sweeps of this generation (the tile keeps TR = H + 4k)
+    const uint32_t sweep_g = sweep0 + (uint32_t)(gen * k);
+    for (int hsi = 0; hsi < 2 * kg; ++hsi) {
+        __syncthreads();
+        set_half_sweep(sweep_g, hsi);
+        // a thread stays on its own octet column and walks every RL-th row pair of the half-sweep's range
+        if (al < RL) run(par0, c.tr_lo + 2 * al, c.tr_lo + 2 * c.npairs, 2 * RL, oct, cq);
+    }
+    __syncthreads();
+    if (RESIDENT && gen + 1 < n_gen) {
+        publish(gen);
+        fetch(gen);
         __syncthreads();
         if (s_fail) return;  // nothing is stored: the source buffer stays valid
-        RES_MARK(3);
     }
+    RES_MARK(0);
     }  // generations
     if (timing)
         for (int q = 0; q < 4; ++q) R->dbg[4 * blockIdx.x + q] = tl[q];
@@ -1005,7 +1029,7 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
         TSU_HIP_TRY(ctx, tsu_func_blocks_per_cu(ctx, (const void*)res_kern, tv.threads,
                                                 tile_lds_bytes(tv, TILE_H + 4 * KMAX), &fit_per_cu));
         if ((long long)ntiles <= (long long)fit_per_cu * ctx->cus) {
-            const size_t xstride = (size_t)4 * (2 * kmax * TILE_WO) + (size_t)4 * res_th;
+            const size_t xstride = (size_t)2 * (2 * kmax * TILE_WO) + (size_t)2 * res_th;  // TOP, BOTTOM, LEFT, RIGHT of colour plane 1
             const size_t xneed = (size_t)2 * ntiles * xstride;
             if (L->xbuf_cap < xneed) {
                 if (L->d_xbuf) (void)hipFree(L->d_xbuf);
