@@ -1,4 +1,5 @@
-"""Open against periodic boundaries on the tile-resident kernel (the open forms spill a few VGPRs)."""
+"""Open against periodic boundaries on the tile-resident kernel (the open forms carry the degree-3 / degree-2 threshold patches
+and the edge masks: 126 VGPRs, no spills since the strip exchange moves one colour plane only)."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tsu-emulator_amd"))
 from tsu import _hip
