@@ -11,7 +11,8 @@ public entry points with seeded inputs, and stores ONLY arrays (inputs, the RNG 
 run consumed, and outputs) as .npz files.  No reference source text or bytecode is stored.
 
 Fixture ids follow SURVEY.md section 8(c): G1..G9; G10 (equilibrium observables of the reference's own sampler at
-T = 2.0, T_c, 2.5 on 16 x 16 and 32 x 32 lattices, ~15 minutes on 7 cores) pins the acceptance criterion of BASELINE.json.
+T = 2.0, T_c, 2.5 on 16 x 16 and 32 x 32 lattices, ~15 minutes on 7 cores) pins the acceptance criterion of BASELINE.json;
+G11 / G12: the reference's own sampling / optimisation benchmark runs (seed 42, quick and full).
 """
 import os
 import sys
@@ -370,8 +371,46 @@ def g11():
     save("g11_sampling_benchmark", **arrs)
 
 
+def g12():
+    """tsu.benchmarks.optimization.OptimizationBenchmark(seed=42).run_all_benchmarks(quick) of the reference, quick and full mode:
+    every trial's objective and the greedy bound (the timing fields are the reference's CPU and are stored for information only),
+    plus the inputs each case drew (graph / numbers) so that the host-side arithmetic can be checked without a GPU."""
+    import contextlib
+    import io
+    from tsu.benchmarks.optimization import OptimizationBenchmark
+    arrs = {}
+    for quick in (True, False):
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = OptimizationBenchmark(seed=42).run_all_benchmarks(quick=quick)
+        for name, r in res.items():
+            key = f"{'quick' if quick else 'full'}_{name}"
+            arrs[key + "_problem"] = np.array(r.problem_name)
+            arrs[key + "_size"] = r.problem_size
+            arrs[key + "_n_trials"] = r.n_trials
+            arrs[key + "_best_objectives"] = np.array(r.best_objectives)
+            arrs[key + "_final_objectives"] = np.array(r.final_objectives)
+            arrs[key + "_optimal_objective"] = np.array(np.nan if r.optimal_objective is None else r.optimal_objective)
+            arrs[key + "_n_iterations"] = np.array(r.n_iterations)
+            arrs[key + "_solution_times"] = np.array(r.solution_times)
+            summ = r.summary()
+            arrs[key + "_summary_keys"] = np.array(sorted(summ.keys()))
+            arrs[key + "_gap_mean"] = np.array(summ.get("optimality_gap_percent", {}).get("mean", np.nan))
+            print(key, "best", r.best_objectives, "optimal", r.optimal_objective, "ms", np.mean(r.solution_times) * 1e3)
+    # the inputs of the two graph cases and of the partition case, as the seeded draws give them (quick and full sizes)
+    for n, dens, tag in ((15, 0.5, "quick_maxcut"), (20, 0.5, "full_maxcut"), (10, 0.4, "quick_coloring"), (15, 0.4, "full_coloring")):
+        np.random.seed(42)
+        a = (np.random.rand(n, n) < dens).astype(float)
+        a = (a + a.T) / 2
+        np.fill_diagonal(a, 0)
+        arrs[tag + "_adjacency"] = a
+    for n, tag in ((15, "quick_partition"), (20, "full_partition")):
+        np.random.seed(42)
+        arrs[tag + "_numbers"] = np.random.randint(1, 100, size=n)
+    save("g12_optimization_benchmark", **arrs)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
-    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10, g11):
+    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12):
         if not only or fn.__name__ in only:
             fn()

@@ -2,12 +2,14 @@
 
 Reference: /root/reference/tsu/benchmarks/runner.py:16-102 (run_all), :155-191 (_save_results): results are kept as
 ``{category: {benchmark: result}}`` and saved as ``benchmark_results.json`` holding every result's ``summary()`` plus a
-plain-text report.  Here the only category is ``"sampling"`` (optimisation / ML / framework comparison are outside the
-scope table); the file names and the JSON layout are the reference's."""
+plain-text report.  Here the categories are ``"sampling"`` (times ``sample_boltzmann``) and ``"optimization"`` (times
+``simulated_annealing``) -- the two suites that call the hot path; ML / framework comparison are outside the scope table
+(SURVEY.md section 8).  The file names and the JSON layout are the reference's."""
 import json
 import time
 from pathlib import Path
 
+from .optimization import OptimizationBenchmark
 from .sampling import SamplingBenchmark
 
 
@@ -31,6 +33,7 @@ class BenchmarkRunner:
     def run_all(self, quick: bool = False, save_results: bool = True, verbose: bool = True):
         t0 = time.time()
         self.results["sampling"] = SamplingBenchmark(seed=self.seed, rng=self.rng).run_all_benchmarks(quick=quick, verbose=verbose)
+        self.results["optimization"] = OptimizationBenchmark(seed=self.seed, rng=self.rng).run_all_benchmarks(quick=quick, verbose=False)
         self.total_time = time.time() - t0
         if verbose:
             self._print_summary()
@@ -47,6 +50,11 @@ class BenchmarkRunner:
             s = res.summary()
             print(f"  {s['distribution']:25s}: KL={s['kl_divergence']['mean']:.4f}, ESS={s['effective_sample_size']['mean']:.0f}, "
                   f"Rate={s['throughput_samples_per_sec']['mean']:.0f}/s")
+        print("OPTIMIZATION BENCHMARKS:")
+        for res in self.results["optimization"].values():
+            s = res.summary()
+            gap = f", Gap={s['optimality_gap_percent']['mean']:.2f}%" if "optimality_gap_percent" in s else ""
+            print(f"  {s['problem']:20s} (n={s['size']}): Time={s['solution_time_ms']['mean']:.1f}ms{gap}")
 
     def _save_results(self):
         data = self.serializable()
@@ -62,7 +70,7 @@ class BenchmarkRunner:
 
 def main(argv=None):
     import argparse
-    ap = argparse.ArgumentParser(description="Run the sampling benchmarks on the MI355X backend")
+    ap = argparse.ArgumentParser(description="Run the sampling and optimisation benchmarks on the MI355X backend")
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--output-dir", default="visual_output")
