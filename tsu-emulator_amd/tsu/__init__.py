@@ -3,8 +3,9 @@
 Scope: ``tsu.gibbs`` (GibbsSampler sweep), ``tsu.models.ising`` (IsingGrid /
 "IsingModel2D" lattice sweep) and ``tsu.core`` (ThermalSamplingUnit Langevin step), with the reference's names,
 signatures and error behaviour, executed by hand-written HIP kernels for gfx950 (``tsu/_lib/libtsu_hip.so``,
-C ABI in ``include/tsu_hip.h``) through ctypes.  The reference's other sub-packages (api, ml, visualization,
-benchmarks, demos, cli) are callers of this path and are not part of this package.
+C ABI in ``include/tsu_hip.h``) through ctypes.  Of the reference's other sub-packages only the two benchmark suites that
+time this path are mirrored (``tsu.benchmarks``: sampling, optimisation, runner); api, ml, visualization, demos and cli are
+callers of this path and are not part of this package.
 """
 
 __version__ = "0.1.0"
