@@ -1,5 +1,5 @@
 """Per-tile timeline of the tile-resident lattice kernel (TSU_K1_VERBOSE=3 prints it from the library): where a generation's
-time goes on every tile, and whether one XCD runs behind the others.  usage: python tools/resident_timeline.py [L ...]"""
+time goes on every tile, and whether one XCD runs behind the others.  usage: python tools/resident_timeline.py [L ...]   (OPEN=1: open boundaries)"""
 import os
 import sys
 
@@ -10,7 +10,7 @@ from tsu import _hip  # noqa: E402
 
 ctx = _hip.Context(0)
 for L in [int(a) for a in sys.argv[1:]] or [4096, 8192]:
-    lat = _hip.Lattice(L, L, True, ctx=ctx)
+    lat = _hip.Lattice(L, L, os.environ.get("OPEN", "0") != "1", ctx=ctx)
     lat.randomize(1)
     lat.set_thresholds(_hip.ising2d_thresholds(1.0, 0.0, 2.269185))
     for rep in range(3):
