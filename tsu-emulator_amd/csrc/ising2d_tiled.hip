@@ -910,6 +910,34 @@ int pick_variant(const tsu_ising2d* L) {
     }
     return v;
 }
+// Tile height of a launch-per-k-sweeps run over a WHOLE lattice: any even height the variant's LDS share holds gives the same
+// results, so it is chosen for the schedule.  The chip runs `slots` tiles at a time and a tile costs about (th + 2k + 12) row
+// times (its trapezoid of halo rows, its stage and store), so a lattice costs ceil(tiles / slots) rounds of that: 10000^2 in
+// 256-row nibble tiles is 800 tiles on 512 slots -- two rounds, the second 56 % full; in 198-row tiles it is 1020 tiles, two
+// full rounds of shorter tiles (-21 %).  Lattices with fewer tiles than slots get shorter tiles so that every slot has one.
+int schedule_tile_h(const tsu_ising2d* L, const TileVariant& tv, int k, int tiles_x) {
+    static int flexible = -1;
+    if (flexible < 0) {
+        const char* e = getenv("TSU_K1_FLEX_TILES");
+        flexible = e ? atoi(e) : 1;
+    }
+    if (!flexible) return tv.H;
+    const int per_cu = tv.per_cu ? tv.per_cu : (tv.threads >= 1024 ? 1 : 2);
+    const long long slots = (long long)per_cu * (L->ctx->cus > 0 ? L->ctx->cus : 256);
+    const size_t lds_share = (size_t)(160 / per_cu) * 1024;
+    int best_th = tv.H;
+    double best = 1e300;
+    for (int th = 32; th <= 1024; th += 2) {
+        if (th + 4 * KMAX > L->total_rows || tile_lds_bytes(tv, th + 4 * k) > lds_share) continue;
+        const long long nt = (long long)((L->rows + th - 1) / th) * tiles_x, rounds = (nt + slots - 1) / slots;
+        const double cost = (double)rounds * (th + 2 * k + 12);
+        if (cost < best * (1.0 - 1e-9) || (cost <= best * (1.0 + 1e-9) && th > best_th)) {
+            best = cost;
+            best_th = th;
+        }
+    }
+    return best_th;
+}
 }  // namespace
 
 int tsu_ising2d_tiled_supported(const tsu_ising2d* L) {
@@ -1152,6 +1180,13 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
         p.dst = L->alloc[L->cur ^ 1] + (size_t)L->ghost * L->pitch;
         int TR = TILE_H + 4 * k;
         size_t lds_bytes = tile_lds_bytes(tv, TR);
+        if (!slab && part == TSU_PART_ALL) {
+            const int th = schedule_tile_h(L, tv, k, p.tiles_x);
+            p.tile_h = th;
+            tiles_y = (L->rows + th - 1) / th;
+            TR = th + 4 * k;
+            lds_bytes = tile_lds_bytes(tv, TR);
+        }
         if (slab && part == TSU_PART_ALL) {
             const int ext = 2 * (n_sweeps - done - k);  // rows of ghost the remaining sweeps of this refresh period need
             p.r_begin = -ext;
