@@ -17,6 +17,10 @@ for case in range(int(os.environ.get("FUZZ_CASES", "60"))):
     if periodic and os.environ.get("FUZZ_RAGGED"):  # periodic lattices of any even width / height: the wrap falls inside an octet
         cols = 2 * random.randint(65, 1100)
         rows = 2 * random.randint(32, 600)
+    if os.environ.get("FUZZ_FLEX"):  # periodic, width a multiple of 16, any even height: with TSU_K1_FLEX_MAX_TILES=6..20 in the
+        periodic = True              # environment these take the flexible tile-resident cut (unequal tile rows, partial last column)
+        cols = 16 * random.randint(17, 140)
+        rows = 2 * random.randint(40, 700)
     if periodic and (rows % 2 or cols % 2):
         continue
     k = random.choice([0, 1, 3, 5, 8])

@@ -30,6 +30,8 @@ struct TiledParams {
     int cols;
     int q_shift;                 // first octet of tile column 0 (periodic lattices of ragged width: keeps the ragged octet out of every halo)
     int tile_h;                  // tile height of this launch (even; the template H is the default and the LDS budget)
+    int flex_ty;                 // > 0: the rows [r_begin, r_end) are cut into flex_ty tile rows of (nearly) equal even heights
+                                 // <= tile_h instead of rows of tile_h each (tile-resident runs of lattices of any height)
     int r_begin, r_end;          // rows this launch computes: [0, rows) or, for a slab that will sweep again before its
                                  // next ghost refresh, [-ext, rows + ext) so that its own halo stays exact
     long long row0, total_rows;  // global row of owned row 0; global lattice height
@@ -398,7 +400,13 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
                                                  const PhiloxKeys& K, const ResidentParams* R = nullptr) {
     constexpr int NO = WO + 2;
     constexpr int RLMAX = THREADS / NO;
-    const int H = p.tile_h;
+    // tile row ty: rows [row_off, row_off + H) of the launch's range
+    int H = p.tile_h, row_off = ty * p.tile_h;
+    if (p.flex_ty > 0) {
+        const long long half = (p.r_end - p.r_begin) / 2;
+        row_off = 2 * (int)(ty * half / p.flex_ty);
+        H = 2 * (int)((ty + 1) * half / p.flex_ty) - row_off;
+    }
     const int TR = H + 4 * k;
     // Row lanes: threads [0, RL*NO) sweep (thread = one octet column x every RL-th row pair); all threads load and
     // store.  What a half-sweep costs is the busiest SIMD's sum of wave-iterations: with every lane in use the last,
@@ -414,7 +422,7 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
     const int tid = threadIdx.x;
     if (tid < 25) s_thr[tid] = p.thr[tid];
 
-    const int q0 = tx * WO + p.q_shift, r0 = p.r_begin + ty * H, Rb = r0 - 2 * k;
+    const int q0 = tx * WO + p.q_shift, r0 = p.r_begin + row_off, Rb = r0 - 2 * k;
 
     // a thread owns one octet column (al = row lane, oct = column) in all three phases: no div/mod in any loop
     const int al = tid / NO, oct = tid - al * NO;
@@ -546,7 +554,11 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
     // number; the host clears the buffer when the numbering restarts or the strip layout changes.)
     // (nibble planes: an element is the octet's dword, the number sits above it in bits 32..45)
     const int n_tb = 2 * k * WO, n_lr = H;  // elements of a top/bottom and of a left/right strip
-    const int xstride = 2 * n_tb + 2 * n_lr;
+    const int xstride = 2 * n_tb + 2 * p.tile_h;  // (tile rows of a flexible cut differ by two rows: one slot size for all)
+    // The last tile column of a lattice whose width is not a multiple of the tile width holds wi < WO lattice octets: its last
+    // interior octet is tile octet wi, its right halo tile octet wi + 1; what lies beyond is the lattice's periodic continuation
+    // from the stage, computed along and never read by anything that counts (it decays like the far side of any halo octet).
+    const int wi = (p.nchunks + p.q_shift - q0) < WO ? (p.nchunks + p.q_shift - q0) : WO;
     constexpr uint64_t TAG_MASK = NIB ? 0xFFFFFFFF00000000ull : 0xFEFEull, FLAG_MASK = NIB ? 0x11111111ull : 0x0101010101010101ull;
     auto strip_tag = [&](int gen) -> uint64_t {
         const uint32_t G = R->gen0 + (uint32_t)gen;
@@ -565,7 +577,7 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
         }
         for (int i = tid; i < n_lr; i += THREADS) {
             xst(mine + 2 * n_tb + i, (uint64_t)plane1[(2 * k + i) * NO + 1] | tag);          // LEFT: first interior octet
-            xst(mine + 2 * n_tb + n_lr + i, (uint64_t)plane1[(2 * k + i) * NO + WO] | tag);  // RIGHT: last interior octet
+            xst(mine + 2 * n_tb + n_lr + i, (uint64_t)plane1[(2 * k + i) * NO + wi] | tag);  // RIGHT: last interior octet
         }
         RES_MARK(1);
     };
@@ -575,6 +587,7 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
         const int tiles_x = p.tiles_x, tiles_y = R->tiles_y, ntiles = tiles_x * tiles_y;
         const uint64_t tag = strip_tag(gen);
         const int txl = tx == 0 ? tiles_x - 1 : tx - 1, txr = tx == tiles_x - 1 ? 0 : tx + 1;
+        const int w_l = txl == tiles_x - 1 ? p.nchunks + p.q_shift - (txl * WO + p.q_shift) : WO;  // lattice octets of the tile column to the left
         const int tyu = ty == 0 ? tiles_y - 1 : ty - 1, tyd = ty == tiles_y - 1 ? 0 : ty + 1;
         const bool has_u = R->wrap_y || ty > 0, has_d = R->wrap_y || ty < tiles_y - 1;
         const bool has_l = R->wrap_x || tx > 0, has_r = R->wrap_x || tx < tiles_x - 1;
@@ -603,9 +616,10 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
             const int i = tid + it * THREADS, ic = i < 2 * k * NO ? i : 0;
             const int r = ic / NO, o = ic - r * NO;
             const int e = r * WO;
-            au[it] = o == 0 ? X_ul + n_tb + e + WO - 1 : (o == NO - 1 ? X_ur + n_tb + e : X_u + n_tb + e + o - 1);
-            ad[it] = o == 0 ? X_dl + e + WO - 1 : (o == NO - 1 ? X_dr + e : X_d + e + o - 1);
-            const bool col_ok = o == 0 ? has_l : (o == NO - 1 ? has_r : true);
+            const int oc = o <= wi + 1 ? o : 1;  // (octets beyond the right halo: nothing is fetched for them)
+            au[it] = oc == 0 ? X_ul + n_tb + e + w_l - 1 : (oc == wi + 1 ? X_ur + n_tb + e : X_u + n_tb + e + oc - 1);
+            ad[it] = oc == 0 ? X_dl + e + w_l - 1 : (oc == wi + 1 ? X_dr + e : X_d + e + oc - 1);
+            const bool col_ok = o == 0 ? has_l : (o == wi + 1 ? has_r : o <= wi);
             nu[it] = i < 2 * k * NO && has_u && col_ok;
             nd[it] = i < 2 * k * NO && has_d && col_ok;
             vu[it] = xld(au[it]);
@@ -656,7 +670,7 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
             const int i = tid + it * THREADS;
             if (i < n_lr) {
                 if (nl[it]) plane1[(2 * k + i) * NO] = (E)(vl[it] & FLAG_MASK);
-                if (nr[it]) plane1[(2 * k + i) * NO + NO - 1] = (E)(vr[it] & FLAG_MASK);
+                if (nr[it]) plane1[(2 * k + i) * NO + wi + 1] = (E)(vr[it] & FLAG_MASK);
             }
         }
         RES_MARK(3);
@@ -833,6 +847,54 @@ int ragged_shift(const tsu_ising2d* L, int WO) {
     return -1;
 }
 
+// Tile-resident runs of whole periodic lattices of ANY even height whose width is a multiple of 16 (flexible cut): the rows are
+// cut into tiles_y tile rows of (nearly) equal even heights and the last tile column may hold fewer octets than the others, so
+// the lattice need not divide into whole tiles.  As many tile rows as the chip has room for (every tile needs its own
+// workgroup; more tiles = shorter tiles = a shorter generation), the tile shape by the generation-time model of pick_variant.
+// Returns tiles_y (0: no such cut) for variant v, or searches the variants when v < 0 and returns the best through *v_out.
+int flex_plan(const tsu_ising2d* L, int v, int* v_out, int* hmax_out) {
+    static int flexible = -1;
+    if (flexible < 0) {
+        const char* e = getenv("TSU_K1_FLEX_TILES");
+        flexible = e ? atoi(e) : 1;
+    }
+    if (!flexible || !L->periodic || L->cols % 16 != 0 || L->ghost != 0 || L->total_rows != L->rows || (L->rows & 1)) return 0;
+    static int use_nib = -1;
+    if (use_nib < 0) {
+        const char* e = getenv("TSU_K1_NIBBLE");
+        use_nib = e ? atoi(e) : 1;
+    }
+    static int max_tiles = -1;  // development / test switch: pretend the chip has room for this many tiles only
+    if (max_tiles < 0) {
+        const char* e = getenv("TSU_K1_FLEX_MAX_TILES");
+        max_tiles = e ? atoi(e) : 0;
+    }
+    int cus = L->ctx->cus > 0 ? L->ctx->cus : 256;
+    if (max_tiles > 0 && max_tiles < cus) cus = max_tiles;
+    const int nch = L->cols / 16;
+    static const int cand[] = {V_256x512_T1024, V_128x256_T1024, V_N512x512_T1024};
+    double best = 1e300;
+    int best_ty = 0;
+    for (int ci = 0; ci < (int)(sizeof(cand) / sizeof(cand[0])); ++ci) {
+        if (v >= 0 && cand[ci] != v) continue;
+        const TileVariant& c = kVariants[cand[ci]];
+        if (!c.resident || (c.nib && !use_nib) || 2 * nch < c.WO) continue;
+        const int tiles_x = (nch + c.WO - 1) / c.WO, tiles_y = cus / tiles_x;
+        if (tiles_y < 1) continue;
+        const int hmax = 2 * (((L->rows / 2) + tiles_y - 1) / tiles_y), hmin = 2 * ((L->rows / 2) / tiles_y);
+        if (hmin < 32 || L->total_rows < hmax + 4 * KMAX || tile_lds_bytes(c, hmax + 4 * KMAX) > 160 * 1024) continue;
+        const int pairs = (hmax + 4 * 8 - 2) / 2, waves = (pairs * (c.WO + 2) + 63) / 64;
+        const double t_gen = 16.0 * (0.25 + (c.nib ? 1.06 : 1.0) * 0.225 * ((waves + 3) / 4)) + 4.3;
+        if (t_gen < best) {
+            best = t_gen;
+            best_ty = tiles_y;
+            if (v_out) *v_out = cand[ci];
+            if (hmax_out) *hmax_out = hmax;
+        }
+    }
+    return best_ty;
+}
+
 int pick_variant(const tsu_ising2d* L) {
     static int env = -2;
     if (env == -2) {
@@ -893,6 +955,17 @@ int pick_variant(const tsu_ising2d* L) {
             }
         }
     }
+    // a whole periodic lattice that the pick above cannot keep resident in LDS (it does not divide into that shape's tiles, or
+    // has more of them than the chip has room for) takes the flexible cut if one exists
+    if (!(env >= 0 && env < kNumVariants)) {
+        const TileVariant& c = kVariants[v];
+        const int nch = (L->cols + 15) / 16, cus = L->ctx->cus > 0 ? L->ctx->cus : 256;
+        const long long nt = (long long)((L->rows + c.H - 1) / c.H) * ((nch + c.WO - 1) / c.WO);
+        const int per_cu = c.per_cu ? c.per_cu : (c.threads >= 1024 ? 1 : 2);
+        const bool standard_resident = c.resident && L->rows % c.H == 0 && nch % c.WO == 0 && nt <= (long long)per_cu * cus;
+        int fv = -1;
+        if (!standard_resident && flex_plan(L, -1, &fv, nullptr) > 0) v = fv;
+    }
     // a variant must fit the lattice (a tile is a window on the lattice's periodic extension: its octet and row indices
     // wrap at most twice / once) and, for an open lattice, have the OPEN form built; -1 = none does (generic kernel)
     auto fits = [&](int vv) {
@@ -950,8 +1023,12 @@ int tsu_ising2d_tiled_supported(const tsu_ising2d* L) {
 // number of tiles (= workgroups of a tile-resident launch) the lattice is cut into; 0 if the tiled kernel does not apply
 int tsu_ising2d_tiled_tiles(const tsu_ising2d* L) {
     if (!tsu_ising2d_tiled_supported(L)) return 0;
-    const TileVariant& tv = kVariants[pick_variant(L)];
-    return ((L->rows + tv.H - 1) / tv.H) * ((((L->cols + 15) / 16) + tv.WO - 1) / tv.WO);
+    const int v = pick_variant(L);
+    const TileVariant& tv = kVariants[v];
+    const int tiles_x = (((L->cols + 15) / 16) + tv.WO - 1) / tv.WO;
+    const bool divides = L->rows % tv.H == 0 && ((L->cols + 15) / 16) % tv.WO == 0;
+    const int fty = divides ? 0 : flex_plan(L, v, nullptr, nullptr);
+    return (fty > 0 ? fty : (L->rows + tv.H - 1) / tv.H) * tiles_x;
 }
 
 // split (interior / boundary) launches: ghost-row slabs whose tile rows are all full
@@ -998,6 +1075,7 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
     p.r_begin = 0;
     p.r_end = L->rows;
     p.tile_h = TILE_H;
+    p.flex_ty = 0;
     int tiles_y = (L->rows + TILE_H - 1) / TILE_H;
     p.k0 = (uint32_t)seed;
     p.k1 = (uint32_t)(seed >> 32);
@@ -1029,13 +1107,24 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
         const char* e = getenv("TSU_K1_RESIDENT");
         use_resident = e ? atoi(e) : 1;
     }
-    const int ntiles = p.tiles_x * tiles_y;
+    int ntiles = p.tiles_x * tiles_y;
     // whole periodic lattice: tiles of TILE_H rows; periodic slab: its tiles stretched over the ghost rows that the call's
     // later generations need (uniform even height th, th * tiles_y = rows + 2 ext, 2 (n_sweeps - k) <= ext <= ghost)
     int res_th = TILE_H, res_ext = 0;
     void (*const res_kern)(ResidentLaunch) = L->periodic ? tv.resident : tv.resident_open;
-    bool res_ok = use_resident && res_kern && part == TSU_PART_ALL && n_sweeps > kmax && p.nchunks % TILE_WO == 0;
-    if (res_ok && (L->wrap_rows || open_whole)) res_ok = L->rows % TILE_H == 0;
+    bool res_ok = use_resident && res_kern && part == TSU_PART_ALL && n_sweeps > kmax;
+    // whole lattice that does not divide into TILE_H x TILE_WO tiles: the flexible cut (balanced tile rows, partial last column)
+    int flex_ty = 0, flex_h = 0;
+    if (res_ok && (L->wrap_rows || open_whole) && !(L->rows % TILE_H == 0 && p.nchunks % TILE_WO == 0))
+        flex_ty = flex_plan(L, (int)(&tv - kVariants), nullptr, &flex_h);
+    if (flex_ty > 0) {
+        tiles_y = flex_ty;
+        ntiles = p.tiles_x * tiles_y;
+        res_th = flex_h;
+    } else if (res_ok) res_ok = p.nchunks % TILE_WO == 0;
+    if (flex_ty > 0) {
+        // (res_th = the tallest tile row of the cut)
+    } else if (res_ok && (L->wrap_rows || open_whole)) res_ok = L->rows % TILE_H == 0;
     else if (res_ok) {
         const int need = L->rows + 4 * (n_sweeps - kmax);
         res_th = (need + tiles_y - 1) / tiles_y;
@@ -1055,7 +1144,7 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
         int fit_per_cu = 0;
         // (occupancy for the standard tile height; a stretched slab tile was checked against the variant's LDS share)
         TSU_HIP_TRY(ctx, tsu_func_blocks_per_cu(ctx, (const void*)res_kern, tv.threads,
-                                                tile_lds_bytes(tv, TILE_H + 4 * KMAX), &fit_per_cu));
+                                                tile_lds_bytes(tv, (flex_ty > 0 ? res_th : TILE_H) + 4 * KMAX), &fit_per_cu));
         if ((long long)ntiles <= (long long)fit_per_cu * ctx->cus) {
             const size_t xstride = (size_t)2 * (2 * kmax * TILE_WO) + (size_t)2 * res_th;  // TOP, BOTTOM, LEFT, RIGHT of colour plane 1
             const size_t xneed = (size_t)2 * ntiles * xstride;
@@ -1068,7 +1157,7 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
                 L->xsig = 0;  // fresh memory: cleared before its first use below
             }
             // strip layout of this call: the element numbering may only run on while it stays the same
-            const uint64_t xsig = ((uint64_t)(vi + 1) << 48) ^ ((uint64_t)ntiles << 28) ^ ((uint64_t)kmax << 20) ^ ((uint64_t)res_th << 4) ^ (uint64_t)p.open;
+            const uint64_t xsig = ((uint64_t)(vi + 1) << 48) ^ ((uint64_t)ntiles << 28) ^ ((uint64_t)kmax << 20) ^ ((uint64_t)res_th << 4) ^ ((uint64_t)flex_ty << 36) ^ (uint64_t)p.open;
             if (!L->h_err) {
                 TSU_HIP_TRY(ctx, hipHostMalloc(&L->h_err, sizeof(int), hipHostMallocMapped));
                 *L->h_err = 0;
@@ -1089,6 +1178,7 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
                 p.src = L->alloc[L->cur] + (size_t)L->ghost * L->pitch;
                 p.dst = L->alloc[L->cur ^ 1] + (size_t)L->ghost * L->pitch;
                 p.tile_h = res_th;
+                p.flex_ty = flex_ty;
                 p.r_begin = -res_ext;
                 p.r_end = L->rows + res_ext;
                 P.t = p;
