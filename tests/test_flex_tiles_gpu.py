@@ -43,7 +43,16 @@ def test_byte_tiles_with_unequal_rows_and_a_partial_last_column():
     assert launches[(300, 400)] == 2
 
 
-@pytest.mark.parametrize("L", [4000, 6000])
+def test_ragged_widths_take_the_flexible_cut_on_byte_tiles():
+    # widths that are not a multiple of 16: the wrap falls inside the last octet (SEAM form), the tiling starts at a shifted octet;
+    # 1110 columns = 69 octets + 6 columns, 1000 = 62 octets + 8 columns, 1318 = 82 octets + 6 columns
+    launches = _run(3, 9, [[500, 1110, [20, 21], 2.269185, 8], [302, 1000, [40, 9], 2.0, 8], [418, 1318, [17], 2.5, 8]])
+    assert launches[(500, 1110)] == 2 and launches[(302, 1000)] == 2
+    launches = _run(4, 6, [[300, 410, [18, 40], 2.5, 8], [420, 1000, [25, 16], 2.269185, 8]])
+    assert launches[(300, 410)] == 2
+
+
+@pytest.mark.parametrize("L", [4000, 5000, 6000])
 def test_full_size_lattices_that_do_not_divide_into_tiles_stay_resident_and_equal_the_generic_kernel(L):
     from tsu import _hip
     ctx = _hip.Context.default()

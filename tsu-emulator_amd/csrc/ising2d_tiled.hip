@@ -847,7 +847,8 @@ int ragged_shift(const tsu_ising2d* L, int WO) {
     return -1;
 }
 
-// Tile-resident runs of whole periodic lattices of ANY even height whose width is a multiple of 16 (flexible cut): the rows are
+// Tile-resident runs of whole periodic lattices of ANY even height and width (flexible cut; nibble planes for widths that are a
+// multiple of 16 only): the rows are
 // cut into tiles_y tile rows of (nearly) equal even heights and the last tile column may hold fewer octets than the others, so
 // the lattice need not divide into whole tiles.  As many tile rows as the chip has room for (every tile needs its own
 // workgroup; more tiles = shorter tiles = a shorter generation), the tile shape by the generation-time model of pick_variant.
@@ -858,7 +859,8 @@ int flex_plan(const tsu_ising2d* L, int v, int* v_out, int* hmax_out) {
         const char* e = getenv("TSU_K1_FLEX_TILES");
         flexible = e ? atoi(e) : 1;
     }
-    if (!flexible || !L->periodic || L->cols % 16 != 0 || L->ghost != 0 || L->total_rows != L->rows || (L->rows & 1)) return 0;
+    if (!flexible || !L->periodic || (L->cols & 1) || L->ghost != 0 || L->total_rows != L->rows || (L->rows & 1)) return 0;
+    const bool ragged = L->cols % 16 != 0;  // the wrap falls inside the last octet: byte planes only (SEAM form), tiling shifted by ragged_shift
     static int use_nib = -1;
     if (use_nib < 0) {
         const char* e = getenv("TSU_K1_NIBBLE");
@@ -871,14 +873,14 @@ int flex_plan(const tsu_ising2d* L, int v, int* v_out, int* hmax_out) {
     }
     int cus = L->ctx->cus > 0 ? L->ctx->cus : 256;
     if (max_tiles > 0 && max_tiles < cus) cus = max_tiles;
-    const int nch = L->cols / 16;
+    const int nch = (L->cols + 15) / 16;
     static const int cand[] = {V_256x512_T1024, V_128x256_T1024, V_N512x512_T1024};
     double best = 1e300;
     int best_ty = 0;
     for (int ci = 0; ci < (int)(sizeof(cand) / sizeof(cand[0])); ++ci) {
         if (v >= 0 && cand[ci] != v) continue;
         const TileVariant& c = kVariants[cand[ci]];
-        if (!c.resident || (c.nib && !use_nib) || 2 * nch < c.WO) continue;
+        if (!c.resident || (c.nib && (!use_nib || ragged)) || 2 * nch < c.WO || ragged_shift(L, c.WO) < 0) continue;
         const int tiles_x = (nch + c.WO - 1) / c.WO, tiles_y = cus / tiles_x;
         if (tiles_y < 1) continue;
         const int hmax = 2 * (((L->rows / 2) + tiles_y - 1) / tiles_y), hmin = 2 * ((L->rows / 2) / tiles_y);
