@@ -52,13 +52,26 @@ def test_ragged_widths_take_the_flexible_cut_on_byte_tiles():
     assert launches[(300, 410)] == 2
 
 
+def test_open_lattices_of_any_shape_take_the_flexible_cut():
+    # open boundaries (the reference's IsingGrid default): odd heights and widths too -- 501 rows over 3 tile rows = 168 + 168 + 165
+    launches = _run(3, 9, [[501, 1111, [20, 21], 2.269185, 8, 0], [333, 1000, [40, 9], 2.0, 8, 0], [410, 530, [17], 2.5, 8, 0]])
+    assert launches[(501, 1111)] == 2 and launches[(333, 1000)] == 2
+    launches = _run(4, 6, [[299, 401, [18, 40], 2.5, 8, 0], [420, 1000, [25, 16], 2.269185, 4, 0]])
+    assert launches[(299, 401)] == 2
+
+
 @pytest.mark.parametrize("L", [4000, 5000, 6000])
-def test_full_size_lattices_that_do_not_divide_into_tiles_stay_resident_and_equal_the_generic_kernel(L):
+@pytest.mark.parametrize("periodic", [True, False])
+def test_full_size_lattices_that_do_not_divide_into_tiles_stay_resident_and_equal_the_generic_kernel(L, periodic):
     from tsu import _hip
     ctx = _hip.Context.default()
     table = _hip.ising2d_thresholds(1.0, 0.0, 2.269185)
-    a = _hip.Lattice(L, L, True, ctx=ctx)
-    b = _hip.Lattice(L, L, True, ctx=ctx)
+    if not periodic:
+        L += 1  # odd: 4001, 5001, 6001
+        if L > 5500:
+            pytest.skip("beyond what 256 CUs hold in byte planes: one launch per generation")
+    a = _hip.Lattice(L, L, periodic, ctx=ctx)
+    b = _hip.Lattice(L, L, periodic, ctx=ctx)
     b.set_kernel(_hip.KERNEL_GENERIC, 0)
     for lat in (a, b):
         lat.randomize(7)

@@ -3,7 +3,7 @@ sys.path.insert(0, "/root/repo/tsu-emulator_amd")
 from tsu import _hip
 ctx = _hip.Context(0)
 for L in [int(a) for a in sys.argv[1:]] or (5000, 6000, 7000, 3000, 10000, 12000):
-    lat = _hip.Lattice(L, L, True, ctx=ctx)
+    lat = _hip.Lattice(L, L, os.environ.get("OPEN", "0") != "1", ctx=ctx)
     lat.randomize(1); lat.set_thresholds(_hip.ising2d_thresholds(1.0, 0.0, 2.269185))
     n = 240
     for _ in range(3): lat.sweep(n, 7, 0)

@@ -403,7 +403,7 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
     // tile row ty: rows [row_off, row_off + H) of the launch's range
     int H = p.tile_h, row_off = ty * p.tile_h;
     if (p.flex_ty > 0) {
-        const long long half = (p.r_end - p.r_begin) / 2;
+        const long long half = (p.r_end - p.r_begin + 1) / 2;  // (an open lattice of odd height: the last tile row ends one row past it)
         row_off = 2 * (int)(ty * half / p.flex_ty);
         H = 2 * (int)((ty + 1) * half / p.flex_ty) - row_off;
     }
@@ -859,7 +859,8 @@ int flex_plan(const tsu_ising2d* L, int v, int* v_out, int* hmax_out) {
         const char* e = getenv("TSU_K1_FLEX_TILES");
         flexible = e ? atoi(e) : 1;
     }
-    if (!flexible || !L->periodic || (L->cols & 1) || L->ghost != 0 || L->total_rows != L->rows || (L->rows & 1)) return 0;
+    if (!flexible || L->ghost != 0 || L->total_rows != L->rows) return 0;
+    if (L->periodic && ((L->cols & 1) || (L->rows & 1))) return 0;  // (odd periodic lattices are not bipartite: generic kernel)
     const bool ragged = L->cols % 16 != 0;  // the wrap falls inside the last octet: byte planes only (SEAM form), tiling shifted by ragged_shift
     static int use_nib = -1;
     if (use_nib < 0) {
@@ -880,10 +881,11 @@ int flex_plan(const tsu_ising2d* L, int v, int* v_out, int* hmax_out) {
     for (int ci = 0; ci < (int)(sizeof(cand) / sizeof(cand[0])); ++ci) {
         if (v >= 0 && cand[ci] != v) continue;
         const TileVariant& c = kVariants[cand[ci]];
-        if (!c.resident || (c.nib && (!use_nib || ragged)) || 2 * nch < c.WO || ragged_shift(L, c.WO) < 0) continue;
+        if (!(L->periodic ? c.resident : c.resident_open) || (c.nib && (!use_nib || ragged)) || 2 * nch < c.WO || ragged_shift(L, c.WO) < 0) continue;
         const int tiles_x = (nch + c.WO - 1) / c.WO, tiles_y = cus / tiles_x;
         if (tiles_y < 1) continue;
-        const int hmax = 2 * (((L->rows / 2) + tiles_y - 1) / tiles_y), hmin = 2 * ((L->rows / 2) / tiles_y);
+        // (an open lattice may have an odd number of rows: the cut is made over rows + 1, the last tile row holds one row less)
+        const int half = (L->rows + 1) / 2, hmax = 2 * ((half + tiles_y - 1) / tiles_y), hmin = 2 * (half / tiles_y);
         if (hmin < 32 || L->total_rows < hmax + 4 * KMAX || tile_lds_bytes(c, hmax + 4 * KMAX) > 160 * 1024) continue;
         const int pairs = (hmax + 4 * 8 - 2) / 2, waves = (pairs * (c.WO + 2) + 63) / 64;
         const double t_gen = 16.0 * (0.25 + (c.nib ? 1.06 : 1.0) * 0.225 * ((waves + 3) / 4)) + 4.3;
