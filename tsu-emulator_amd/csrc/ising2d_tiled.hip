@@ -853,7 +853,7 @@ int ragged_shift(const tsu_ising2d* L, int WO) {
 // the lattice need not divide into whole tiles.  As many tile rows as the chip has room for (every tile needs its own
 // workgroup; more tiles = shorter tiles = a shorter generation), the tile shape by the generation-time model of pick_variant.
 // Returns tiles_y (0: no such cut) for variant v, or searches the variants when v < 0 and returns the best through *v_out.
-int flex_plan(const tsu_ising2d* L, int v, int* v_out, int* hmax_out) {
+int flex_plan(const tsu_ising2d* L, int v, int* v_out, int* hmax_out, double* t_out = nullptr) {
     static int flexible = -1;
     if (flexible < 0) {
         const char* e = getenv("TSU_K1_FLEX_TILES");
@@ -896,10 +896,18 @@ int flex_plan(const tsu_ising2d* L, int v, int* v_out, int* hmax_out) {
             if (hmax_out) *hmax_out = hmax;
         }
     }
+    if (t_out) *t_out = best;
     return best_ty;
 }
 
-int pick_variant(const tsu_ising2d* L) {
+struct TilePlan {
+    int v;        // index into kVariants, -1: none fits (generic kernel)
+    int flex_ty;  // > 0: tile-resident runs use the flexible cut with this many tile rows ...
+    int flex_h;   // ... whose tallest is this high
+};
+
+TilePlan tile_plan(const tsu_ising2d* L) {
+    int flex_ty = 0, flex_h = 0;
     static int env = -2;
     if (env == -2) {
         const char* e = getenv("TSU_TILE_VARIANT");
@@ -961,14 +969,30 @@ int pick_variant(const tsu_ising2d* L) {
     }
     // a whole periodic lattice that the pick above cannot keep resident in LDS (it does not divide into that shape's tiles, or
     // has more of them than the chip has room for) takes the flexible cut if one exists
-    if (!(env >= 0 && env < kNumVariants)) {
+    // ... and so does one that the pick above keeps resident in fewer, taller tiles than the chip has room for (6144^2 in 512-row
+    // nibble tiles: 144 tiles on 256 CUs) when the model gives the flexible cut a generation that is at least 3 % shorter.
+    {
         const TileVariant& c = kVariants[v];
         const int nch = (L->cols + 15) / 16, cus = L->ctx->cus > 0 ? L->ctx->cus : 256;
         const long long nt = (long long)((L->rows + c.H - 1) / c.H) * ((nch + c.WO - 1) / c.WO);
         const int per_cu = c.per_cu ? c.per_cu : (c.threads >= 1024 ? 1 : 2);
-        const bool standard_resident = c.resident && L->rows % c.H == 0 && nch % c.WO == 0 && nt <= (long long)per_cu * cus;
-        int fv = -1;
-        if (!standard_resident && flex_plan(L, -1, &fv, nullptr) > 0) v = fv;
+        const bool divides = L->rows % c.H == 0 && nch % c.WO == 0;
+        const bool standard_resident = (L->periodic ? c.resident : c.resident_open) && divides && nt <= (long long)per_cu * cus;
+        const bool forced = env >= 0 && env < kNumVariants;
+        int fv = -1, fh = 0;
+        double t_flex = 0;
+        const int fty = forced ? (divides ? 0 : flex_plan(L, v, &fv, &fh, &t_flex)) : flex_plan(L, -1, &fv, &fh, &t_flex);
+        bool take = fty > 0 && !standard_resident;
+        if (fty > 0 && standard_resident && !forced && per_cu == 1) {
+            const int pairs = (c.H + 4 * 8 - 2) / 2, waves = (pairs * (c.WO + 2) + 63) / 64;
+            const double t_std = 16.0 * (0.25 + (c.nib ? 1.06 : 1.0) * 0.225 * ((waves + 3) / 4)) + 4.3;
+            take = t_flex < 0.97 * t_std;
+        }
+        if (take) {
+            v = fv;
+            flex_ty = fty;
+            flex_h = fh;
+        }
     }
     // a variant must fit the lattice (a tile is a window on the lattice's periodic extension: its octet and row indices
     // wrap at most twice / once) and, for an open lattice, have the OPEN form built; -1 = none does (generic kernel)
@@ -979,14 +1003,17 @@ int pick_variant(const tsu_ising2d* L) {
     if (!fits(v)) {
         static const int fallback[] = {V_64x512_T512, V_64x256_T1024, V_32x256_T1024};
         v = -1;
+        flex_ty = flex_h = 0;
         for (int f : fallback)
             if (fits(f)) {
                 v = f;
                 break;
             }
     }
-    return v;
+    return TilePlan{v, flex_ty, flex_h};
 }
+
+int pick_variant(const tsu_ising2d* L) { return tile_plan(L).v; }
 // Tile height of a launch-per-k-sweeps run over a WHOLE lattice: any even height the variant's LDS share holds gives the same
 // results, so it is chosen for the schedule.  The chip runs `slots` tiles at a time and a tile costs about (th + 2k + 12) row
 // times (its trapezoid of halo rows, its stage and store), so a lattice costs ceil(tiles / slots) rounds of that: 10000^2 in
@@ -1027,12 +1054,10 @@ int tsu_ising2d_tiled_supported(const tsu_ising2d* L) {
 // number of tiles (= workgroups of a tile-resident launch) the lattice is cut into; 0 if the tiled kernel does not apply
 int tsu_ising2d_tiled_tiles(const tsu_ising2d* L) {
     if (!tsu_ising2d_tiled_supported(L)) return 0;
-    const int v = pick_variant(L);
-    const TileVariant& tv = kVariants[v];
+    const TilePlan plan = tile_plan(L);
+    const TileVariant& tv = kVariants[plan.v];
     const int tiles_x = (((L->cols + 15) / 16) + tv.WO - 1) / tv.WO;
-    const bool divides = L->rows % tv.H == 0 && ((L->cols + 15) / 16) % tv.WO == 0;
-    const int fty = divides ? 0 : flex_plan(L, v, nullptr, nullptr);
-    return (fty > 0 ? fty : (L->rows + tv.H - 1) / tv.H) * tiles_x;
+    return (plan.flex_ty > 0 ? plan.flex_ty : (L->rows + tv.H - 1) / tv.H) * tiles_x;
 }
 
 // split (interior / boundary) launches: ghost-row slabs whose tile rows are all full
@@ -1042,7 +1067,8 @@ int tsu_ising2d_tiled_part_supported(const tsu_ising2d* L) {
 
 int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_t sweep0, uint32_t replica, int part) {
     tsu_ctx* ctx = L->ctx;
-    const TileVariant& tv = kVariants[pick_variant(L)];
+    const TilePlan plan = tile_plan(L);
+    const TileVariant& tv = kVariants[plan.v];
     const int TILE_H = tv.H, TILE_WO = tv.WO;
     if (!L->alloc[1]) {
         size_t bytes = (size_t)(L->rows + 2 * L->ghost) * L->pitch;
@@ -1118,9 +1144,7 @@ int tsu_ising2d_tiled_sweep(tsu_ising2d* L, int n_sweeps, uint64_t seed, uint32_
     void (*const res_kern)(ResidentLaunch) = L->periodic ? tv.resident : tv.resident_open;
     bool res_ok = use_resident && res_kern && part == TSU_PART_ALL && n_sweeps > kmax;
     // whole lattice that does not divide into TILE_H x TILE_WO tiles: the flexible cut (balanced tile rows, partial last column)
-    int flex_ty = 0, flex_h = 0;
-    if (res_ok && (L->wrap_rows || open_whole) && !(L->rows % TILE_H == 0 && p.nchunks % TILE_WO == 0))
-        flex_ty = flex_plan(L, (int)(&tv - kVariants), nullptr, &flex_h);
+    const int flex_ty = res_ok && (L->wrap_rows || open_whole) ? plan.flex_ty : 0, flex_h = plan.flex_h;
     if (flex_ty > 0) {
         tiles_y = flex_ty;
         ntiles = p.tiles_x * tiles_y;
