@@ -867,6 +867,12 @@ int flex_plan(const tsu_ising2d* L, int v, int* v_out, int* hmax_out, double* t_
         const char* e = getenv("TSU_K1_NIBBLE");
         use_nib = e ? atoi(e) : 1;
     }
+    static int FLEX_HMIN = -1;  // shortest tile row of a cut (the strips are 2k = 16 rows deep)
+    if (FLEX_HMIN < 0) {
+        const char* e = getenv("TSU_K1_FLEX_HMIN");
+        FLEX_HMIN = e ? atoi(e) : 16;
+        if (FLEX_HMIN < 16) FLEX_HMIN = 16;
+    }
     static int max_tiles = -1;  // development / test switch: pretend the chip has room for this many tiles only
     if (max_tiles < 0) {
         const char* e = getenv("TSU_K1_FLEX_MAX_TILES");
@@ -882,11 +888,13 @@ int flex_plan(const tsu_ising2d* L, int v, int* v_out, int* hmax_out, double* t_
         if (v >= 0 && cand[ci] != v) continue;
         const TileVariant& c = kVariants[cand[ci]];
         if (!(L->periodic ? c.resident : c.resident_open) || (c.nib && (!use_nib || ragged)) || 2 * nch < c.WO || ragged_shift(L, c.WO) < 0) continue;
-        const int tiles_x = (nch + c.WO - 1) / c.WO, tiles_y = cus / tiles_x;
-        if (tiles_y < 1) continue;
         // (an open lattice may have an odd number of rows: the cut is made over rows + 1, the last tile row holds one row less)
-        const int half = (L->rows + 1) / 2, hmax = 2 * ((half + tiles_y - 1) / tiles_y), hmin = 2 * (half / tiles_y);
-        if (hmin < 32 || L->total_rows < hmax + 4 * KMAX || tile_lds_bytes(c, hmax + 4 * KMAX) > 160 * 1024) continue;
+        const int tiles_x = (nch + c.WO - 1) / c.WO, half = (L->rows + 1) / 2;
+        int tiles_y = cus / tiles_x;
+        if (tiles_y > half / (FLEX_HMIN / 2)) tiles_y = half / (FLEX_HMIN / 2);  // a small lattice: not every CU gets a tile
+        if (tiles_y < 1) continue;
+        const int hmax = 2 * ((half + tiles_y - 1) / tiles_y), hmin = 2 * (half / tiles_y);
+        if (hmin < FLEX_HMIN || L->total_rows < hmax + 4 * KMAX || tile_lds_bytes(c, hmax + 4 * KMAX) > 160 * 1024) continue;
         const int pairs = (hmax + 4 * 8 - 2) / 2, waves = (pairs * (c.WO + 2) + 63) / 64;
         const double t_gen = 16.0 * (0.25 + (c.nib ? 1.06 : 1.0) * 0.225 * ((waves + 3) / 4)) + 4.3;
         if (t_gen < best) {
