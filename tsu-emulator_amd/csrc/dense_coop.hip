@@ -405,8 +405,9 @@ __global__ __launch_bounds__(CO_THREADS) void k2_coop(CoopParams P) {
 //   Hand-offs between the roles are two monotone counters (C1: fields of the next superblock complete; SOLVED: flips of
 //   the superblock final), everything shared goes through agent-scope (sc1) accesses drained before the signal.
 // Superblock size of the pipeline: the fixed costs (hand-offs, commit, the iterations' latency) are per superblock, the
-// exposed strip + triangle bytes and the iteration count grow with it.  Measured (fp32, T = 1, ms per sweep, 4096 / 8192):
-// n = 8192 0.203 / 0.180, 12288 0.296 / 0.285, 16384 0.381 / 0.398 -- 8192 up to n = 12288, 4096 above.
+// exposed strip + triangle bytes and the iteration count grow with it.  Measured on the finished kernel (fp32, T = 1, ms per
+// sweep, superblocks of 2048 / 4096 / 8192): n = 1024 0.053 / 0.059 / 0.068, 2048 0.061 / 0.067 / 0.083, 4096 0.106 / 0.103 / 0.122,
+// 8192 0.185 / 0.170 / 0.190, 12288 0.283 / 0.262 / 0.273, 16384 0.373 / 0.333 / 0.363 -- 2048 for n <= 2048, 4096 above.
 #define PP_SB_MAX 8192
 #define PP_TEAMS 4                // 64-row groups per solver workgroup
 #define PP_GRAN_MAX (PP_SB_MAX / 32)
@@ -452,7 +453,7 @@ template <typename TJ, bool VEC, int SB, int U2>
 __global__ __launch_bounds__(CO_THREADS) void k2_pipe(PipeParams P) {
     // superblock of SB positions: SB / 256 solver workgroups with four 64-row groups each, SB / 32 mask granules
     constexpr int NS = SB / 256, GRAN = SB / 32, GPL = GRAN / 64;
-    static_assert(NS * PP_TEAMS * 64 == SB && (GPL == 2 || GPL == 4), "solver workgroups x 4 groups of 64 rows = one superblock");
+    static_assert(NS * PP_TEAMS * 64 == SB && (GPL == 1 || GPL == 2 || GPL == 4), "solver workgroups x 4 groups of 64 rows = one superblock");
     extern __shared__ int8_t wl[];  // streamers: staged state (n bytes) / staged flips (SB bytes)
     __shared__ double s_f[CO_THREADS / 64][PP_MAXR];
     __shared__ double s_red[CO_THREADS / 64][PP_TEAMS][64];  // partial sums: [wave][group of the workgroup][row]
@@ -819,7 +820,9 @@ static int pipe_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint3
         const char* e = getenv("TSU_K2_PIPE_SB");
         sb_env = e ? atoi(e) : 0;
     }
-    const int sb = (sb_env == 4096 || sb_env == 8192) ? sb_env : (n <= 12288 ? 8192 : 4096);
+    // superblock: 4096 (2048 for systems that fit one): re-measured on the finished pipeline (profiles/r02_k2_notes.txt) -- 8192,
+    // which had won up to n = 12288 half-way through its development, loses everywhere now
+    const int sb = (sb_env == 2048 || sb_env == 4096 || sb_env == 8192) ? sb_env : (n <= 2048 ? 2048 : 4096);
     const int ns = sb / 256;
     if (!use_pipe || n > CO_MAX_N || n < 1024 || grid < 2 * ns) return TSU_OK;
     if ((long long)(grid - ns) * (CO_THREADS / 64) * PP_MAXR < n) return TSU_OK;
@@ -830,6 +833,7 @@ static int pipe_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint3
     // 0.386 -> 0.353 ms per sweep; profiles/r02_k2_notes.txt), eight once the strips dominate
     const bool gentle = n <= 20480;
     void (*kern)(PipeParams) = sb == 8192 ? (vec ? k2_pipe<TJ, true, 8192, 1> : k2_pipe<TJ, false, 8192, 1>)
+                               : sb == 2048 ? (vec ? k2_pipe<TJ, true, 2048, 1> : k2_pipe<TJ, false, 2048, 1>)
                                : gentle   ? (vec ? k2_pipe<TJ, true, 4096, 1> : k2_pipe<TJ, false, 4096, 1>)
                                           : (vec ? k2_pipe<TJ, true, 4096, 8> : k2_pipe<TJ, false, 4096, 8>);
     const size_t lds_bytes = (size_t)((n > sb ? n : sb) + 15) / 16 * 16;
