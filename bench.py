@@ -476,6 +476,10 @@ def main():
             extra["ising2d_32x32"] = time_lattice(hip, ctx, 32, 0, 20000)
             # a width that is not a multiple of 16 (the wrap falls inside an octet): IsingModel2D(1000)
             extra["ising2d_1000x1000"] = time_lattice(hip, ctx, 1000, 0, 4096)
+            # lattices that do not divide into whole tiles stay tile-resident through the flexible cut (balanced tile rows of
+            # different heights, a narrower last tile column): nibble planes at 6000^2, byte planes (ragged width) at 5000^2
+            for L2 in (5000, 6000):
+                extra[f"ising2d_L{L2}"] = time_lattice(hip, ctx, L2, 0, 240)
             extra["langevin_dim_2^20"] = time_langevin(hip, ctx, counters)
             extra["dense_gibbs"] = time_dense(hip, ctx, counters)
             extra["sparse_chain_2^24"] = time_sparse_chain(hip, ctx, counters)
