@@ -58,6 +58,9 @@ def test_open_lattices_of_any_shape_take_the_flexible_cut():
     assert launches[(501, 1111)] == 2 and launches[(333, 1000)] == 2
     launches = _run(4, 6, [[299, 401, [18, 40], 2.5, 8, 0], [420, 1000, [25, 16], 2.269185, 4, 0]])
     assert launches[(299, 401)] == 2
+    # nibble planes, open, flexible cut: 1001 rows over 2 tile rows, 1111 columns = 69 octets + 7 columns
+    launches = _run(8, 6, [[1001, 1111, [20, 21], 2.269185, 8, 0], [603, 1040, [33, 9], 2.0, 8, 0]])
+    assert launches[(1001, 1111)] == 2
 
 
 @pytest.mark.parametrize("L", [4000, 5000, 6000])
@@ -67,9 +70,7 @@ def test_full_size_lattices_that_do_not_divide_into_tiles_stay_resident_and_equa
     ctx = _hip.Context.default()
     table = _hip.ising2d_thresholds(1.0, 0.0, 2.269185)
     if not periodic:
-        L += 1  # odd: 4001, 5001, 6001
-        if L > 5500:
-            pytest.skip("beyond what 256 CUs hold in byte planes: one launch per generation")
+        L += 1  # odd: 4001, 5001, 6001 (the last one in nibble planes: beyond what 256 CUs hold in byte planes)
     a = _hip.Lattice(L, L, periodic, ctx=ctx)
     b = _hip.Lattice(L, L, periodic, ctx=ctx)
     b.set_kernel(_hip.KERNEL_GENERIC, 0)

@@ -32,3 +32,12 @@ def test_nibble_512_row_tiles_resident_and_not():
 def test_nibble_256_row_tiles_two_workgroups_per_cu():
     # variant 9: 256 x 512 tiles, 512 threads, one launch per generation (what lattices beyond 8192^2 run on)
     _run(9, [[512, 512, [3, 8, 13], 2.269185, 8], [768, 1024, [20], 2.0, 8], [300, 512, [7], 2.5, 5], [1280, 2048, [16], 2.269185, 8]])
+
+
+def test_nibble_planes_on_open_lattices_of_any_width():
+    # open boundaries: degree-3 / degree-2 thresholds at the edges, nothing beyond them; widths that are not a multiple of 16
+    _run(9, [[512, 512, [3, 8, 13], 2.269185, 8, 0], [768, 1000, [20], 2.0, 8, 0], [301, 530, [7, 9], 2.5, 5, 0], [1280, 2047, [16], 2.269185, 8, 0]])
+    out = _run(8, [[1024, 1024, [3, 21, 40], 2.269185, 8, 0],   # 2 x 2 tiles of 512 x 512: tile-resident
+                   [1536, 512, [9, 17], 2.0, 4, 0],
+                   [1000, 1111, [5, 20], 2.5, 8, 0]])
+    assert "ok 1024x1024" in out

@@ -326,7 +326,7 @@ static __device__ __forceinline__ uint32_t nib_pack(const u32x4& d) {
     return (uint32_t)f | ((uint32_t)(f >> 32) << 4);
 }
 
-template <int NO, int P0, bool EDGE>
+template <int NO, int P0, bool EDGE, bool OPEN = false>
 static __device__ __forceinline__ void sweep_pairs_nib(const Rows2Ctx& c, const PhiloxKeys& K, int tr_first, int tr_end, int step_rows, int oct,
                                                        uint32_t cq) {
     const char* const ps0 = reinterpret_cast<const char*>(c.Ps);
@@ -356,16 +356,33 @@ static __device__ __forceinline__ void sweep_pairs_nib(const Rows2Ctx& c, const 
         const uint32_t cnt0 = R0 + mid + Sa, cnt1 = R3 + mid + Sb;
         const uint32_t cnt0l = cnt0 & 0x0F0F0F0Fu, cnt0h = (cnt0 >> 4) & 0x0F0F0F0Fu;
         const uint32_t cnt1l = cnt1 & 0x0F0F0F0Fu, cnt1h = (cnt1 >> 4) & 0x0F0F0F0Fu;
-        u32x4 d0 = compare_octet(w0, cnt0l, cnt0h, c.tblH0, c.tblH1, c.tblL0, c.tblL1);
-        u32x4 d1 = compare_octet(w1, cnt1l, cnt1h, c.tblH0, c.tblH1, c.tblL0, c.tblL1);
+        u32x4 d0, d1;
+        uint32_t edge_a = 0, edge_b = 0;
+        if (OPEN) {  // as in sweep_pairs: the counts are bytes by now, the degree-3 / degree-2 patches are the byte form's
+            const bool ea = rga == 0 || rga == c.last_row, eb = rgb == 0 || rgb == c.last_row;
+            const bool la = !P0 && c.lft, ra = c.rgt && c.r_par == (uint32_t)P0, lb = P0 && c.lft, rb = c.rgt && c.r_par != (uint32_t)P0;
+            d0 = compare_octet_open(w0, cnt0l, cnt0h, c, ea, la, ra);
+            d1 = compare_octet_open(w1, cnt1l, cnt1h, c, eb, lb, rb);
+            edge_a = (ea ? 1u : 0u) | (la ? 2u : 0u) | (ra ? 4u : 0u) | (c.r_slot << 4);
+            edge_b = (eb ? 1u : 0u) | (lb ? 2u : 0u) | (rb ? 4u : 0u) | (c.r_slot << 4);
+        } else {
+            d0 = compare_octet(w0, cnt0l, cnt0h, c.tblH0, c.tblH1, c.tblL0, c.tblL1);
+            d1 = compare_octet(w1, cnt1l, cnt1h, c.tblH0, c.tblH1, c.tblL0, c.tblL1);
+        }
         const uint32_t mn = minu16(minu16(minu16(d0.x, d0.y), minu16(d0.z, d0.w)), minu16(minu16(d1.x, d1.y), minu16(d1.z, d1.w)));
         if (__builtin_expect(((mn & 0xFFFFu) == 0) | ((mn >> 16) == 0), 0)) {
-            if (has_zero_field(d0)) d0 = resolve_ties(d0, w0, cnt0l, cnt0h, c.s_thr, cq, (uint32_t)rga, c.hs, c.tag_lo, c.k0, c.k1, 0);
-            if (has_zero_field(d1)) d1 = resolve_ties(d1, w1, cnt1l, cnt1h, c.s_thr, cq, (uint32_t)rgb, c.hs, c.tag_lo, c.k0, c.k1, 0);
+            if (has_zero_field(d0)) d0 = resolve_ties(d0, w0, cnt0l, cnt0h, c.s_thr, cq, (uint32_t)rga, c.hs, c.tag_lo, c.k0, c.k1, edge_a);
+            if (has_zero_field(d1)) d1 = resolve_ties(d1, w1, cnt1l, cnt1h, c.s_thr, cq, (uint32_t)rgb, c.hs, c.tag_lo, c.k0, c.k1, edge_b);
         }
         char* pd = const_cast<char*>(ps) + d_off;
-        *reinterpret_cast<uint32_t*>(pd) = nib_pack(d0);
-        *reinterpret_cast<uint32_t*>(pd + NO * 4) = nib_pack(d1);
+        uint32_t n0 = nib_pack(d0), n1 = nib_pack(d1);
+        if (OPEN) {  // what lies beyond the open edge stays empty (existing-site masks in the nibble layout)
+            const uint64_t ma = P0 ? c.vm_o : c.vm_e, mb = P0 ? c.vm_e : c.vm_o;
+            n0 = (rga < 0 || rga > c.last_row) ? 0u : (n0 & ((uint32_t)ma | ((uint32_t)(ma >> 32) << 4)));
+            n1 = (rgb < 0 || rgb > c.last_row) ? 0u : (n1 & ((uint32_t)mb | ((uint32_t)(mb >> 32) << 4)));
+        }
+        *reinterpret_cast<uint32_t*>(pd) = n0;
+        *reinterpret_cast<uint32_t*>(pd + NO * 4) = n1;
     }
 }
 
@@ -413,7 +430,6 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
     // partial iteration occupies the fewest waves and those are consecutive, i.e. spread round-robin over the four
     // SIMDs (+5 % on 4096^2 against the smallest lane count that reaches the same iteration count).
     constexpr int RL = RLMAX;
-    static_assert(!(NIB && OPEN), "the nibble planes are built for periodic lattices only");
     using E = typename std::conditional<NIB, uint32_t, uint64_t>::type;  // one octet of a colour plane
     E* plane0 = reinterpret_cast<E*>(lds + 1);
     E* plane1 = plane0 + TR * NO;
@@ -678,7 +694,10 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
 
     // one call site for every form of the pair loop: rows tr_first, tr_first + step, ... < tr_end of octet column oc
     auto run = [&](int par0, int tr_first, int tr_end, int step, int oc, uint32_t cqq) {
-        if (NIB) {
+        if (NIB && OPEN) {
+            if (par0) sweep_pairs_nib<NO, 1, false, true>(c, K, tr_first, tr_end, step, oc, cqq);
+            else sweep_pairs_nib<NO, 0, false, true>(c, K, tr_first, tr_end, step, oc, cqq);
+        } else if (NIB) {
             if (edge) {
                 if (par0) sweep_pairs_nib<NO, 1, true>(c, K, tr_first, tr_end, step, oc, cqq);
                 else sweep_pairs_nib<NO, 0, true>(c, K, tr_first, tr_end, step, oc, cqq);
@@ -823,8 +842,9 @@ const TileVariant kVariants[] = {
     {64, 16, 1024, k1_tiled2<64, 16, 1024>, k1_resident<64, 16, 1024>, k1_tiled2<64, 16, 1024, 1, true>, k1_resident<64, 16, 1024, 1, true>},
     {32, 16, 1024, k1_tiled2<32, 16, 1024>, k1_resident<32, 16, 1024>, k1_tiled2<32, 16, 1024, 1, true>, k1_resident<32, 16, 1024, 1, true>},
     // nibble planes: 512 x 512 sites per CU (148 KB) -- 8192^2 tile-resident; 256 x 512, two workgroups per CU, for what is larger still
-    {512, 32, 1024, k1_tiled2<512, 32, 1024, 4, false, true>, k1_resident<512, 32, 1024, 4, false, true>, nullptr, nullptr, 1, 1},
-    {256, 32, 512, k1_tiled2<256, 32, 512, 4, false, true>, nullptr, nullptr, nullptr, 1, 2},
+    {512, 32, 1024, k1_tiled2<512, 32, 1024, 4, false, true>, k1_resident<512, 32, 1024, 4, false, true>, k1_tiled2<512, 32, 1024, 4, true, true>,
+     k1_resident<512, 32, 1024, 4, true, true>, 1, 1},
+    {256, 32, 512, k1_tiled2<256, 32, 512, 4, false, true>, nullptr, k1_tiled2<256, 32, 512, 4, true, true>, nullptr, 1, 2},
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -887,7 +907,7 @@ int flex_plan(const tsu_ising2d* L, int v, int* v_out, int* hmax_out, double* t_
     for (int ci = 0; ci < (int)(sizeof(cand) / sizeof(cand[0])); ++ci) {
         if (v >= 0 && cand[ci] != v) continue;
         const TileVariant& c = kVariants[cand[ci]];
-        if (!(L->periodic ? c.resident : c.resident_open) || (c.nib && (!use_nib || ragged)) || 2 * nch < c.WO || ragged_shift(L, c.WO) < 0) continue;
+        if (!(L->periodic ? c.resident : c.resident_open) || (c.nib && (!use_nib || (L->periodic && ragged))) || 2 * nch < c.WO || ragged_shift(L, c.WO) < 0) continue;
         // (an open lattice may have an odd number of rows: the cut is made over rows + 1, the last tile row holds one row less)
         const int tiles_x = (nch + c.WO - 1) / c.WO, half = (L->rows + 1) / 2;
         int tiles_y = cus / tiles_x;
@@ -944,9 +964,10 @@ TilePlan tile_plan(const tsu_ising2d* L) {
             const char* e = getenv("TSU_K1_NIBBLE");
             use_nib = e ? atoi(e) : 1;
         }
-        const bool nib_ok = use_nib && L->periodic && L->cols % 16 == 0 && L->ghost == 0 && L->total_rows == L->rows;
+        // (open lattices: any width -- no wrap, the ragged last octet is masked like every site beyond the edge)
+        const bool nib_ok = use_nib && (L->periodic ? L->cols % 16 == 0 : true) && L->ghost == 0 && L->total_rows == L->rows;
         if (nib_ok && n128 > 2 * cus) {
-            const int nch_ = L->cols / 16;
+            const int nch_ = (L->cols + 15) / 16;
             const long long n512 = (long long)(L->rows / 512) * (nch_ / 32);
             if (L->rows % 512 == 0 && nch_ % 32 == 0 && n512 <= cus && 2 * n512 > cus) v = V_N512x512_T1024;
             else if (L->rows >= 512) v = V_N256x512_T512;
