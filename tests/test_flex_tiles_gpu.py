@@ -50,6 +50,9 @@ def test_ragged_widths_take_the_flexible_cut_on_byte_tiles():
     assert launches[(500, 1110)] == 2 and launches[(302, 1000)] == 2
     launches = _run(4, 6, [[300, 410, [18, 40], 2.5, 8], [420, 1000, [25, 16], 2.269185, 8]])
     assert launches[(300, 410)] == 2
+    # the same on nibble planes (SEAM form of the nibble loop)
+    launches = _run(8, 6, [[1000, 1110, [20, 21], 2.269185, 8], [604, 1000, [33, 9], 2.0, 8], [614, 1318, [24], 2.5, 8]])
+    assert launches[(1000, 1110)] == 2
 
 
 def test_open_lattices_of_any_shape_take_the_flexible_cut():
@@ -63,7 +66,7 @@ def test_open_lattices_of_any_shape_take_the_flexible_cut():
     assert launches[(1001, 1111)] == 2
 
 
-@pytest.mark.parametrize("L", [4000, 5000, 6000])
+@pytest.mark.parametrize("L", [4000, 5000, 6000, 7000])
 @pytest.mark.parametrize("periodic", [True, False])
 def test_full_size_lattices_that_do_not_divide_into_tiles_stay_resident_and_equal_the_generic_kernel(L, periodic):
     from tsu import _hip

@@ -41,3 +41,11 @@ def test_nibble_planes_on_open_lattices_of_any_width():
                    [1536, 512, [9, 17], 2.0, 4, 0],
                    [1000, 1111, [5, 20], 2.5, 8, 0]])
     assert "ok 1024x1024" in out
+
+
+def test_nibble_planes_on_periodic_lattices_of_ragged_width():
+    # widths that are not a multiple of 16: the wrap falls inside the last octet (SEAM form of the nibble loop); 1000 = 62 octets + 8
+    # columns (4 sites per colour in the last octet), 1110 = 69 + 6 (3 sites), 530 = 33 + 2 (1 site), 2046 = 127 + 14 (7 sites)
+    _run(9, [[512, 1000, [3, 8, 13], 2.269185, 8], [768, 1110, [20], 2.0, 8], [300, 530, [7, 9], 2.5, 5], [1280, 2046, [16], 2.269185, 8],
+             [600, 1004, [11], 2.269185, 8], [600, 1012, [11], 3.0, 8]])
+    _run(8, [[1024, 1000, [3, 21, 40], 2.269185, 8], [1000, 1110, [5, 20], 2.5, 8], [1536, 530, [9, 17], 2.0, 4]])

@@ -321,12 +321,21 @@ static __device__ __forceinline__ uint32_t nib_shift_prev(uint32_t X, uint32_t M
     const uint32_t w = ((X << 4) & 0x10000000u) | (M >> 4);
     return __builtin_amdgcn_alignbit(X, w, 24);
 }
+// SEAM (periodic width not a multiple of 16, see sweep_pairs): the octet that crosses over sits at site v - 1 of the ragged
+// last octet instead of site 7 -- bit position `pos` = 8 (j & 3) + 4 (j >> 2) of site j (28 for every other octet)
+static __device__ __forceinline__ uint32_t nib_shift_next_seam(uint32_t X, uint32_t N, int pos) {
+    return nib_shift_next(X, 0u) | ((N & 0xFu) << pos);  // (site v of a ragged octet is empty, so the slot is free)
+}
+static __device__ __forceinline__ uint32_t nib_shift_prev_seam(uint32_t X, uint32_t M, int pos) {
+    const uint32_t w = ((X << 4) & 0x10000000u) | (((M >> pos) & 0xFu) << 24);
+    return __builtin_amdgcn_alignbit(X, w, 24);
+}
 static __device__ __forceinline__ uint32_t nib_pack(const u32x4& d) {
     const uint64_t f = pack_flags(d);
     return (uint32_t)f | ((uint32_t)(f >> 32) << 4);
 }
 
-template <int NO, int P0, bool EDGE, bool OPEN = false>
+template <int NO, int P0, bool EDGE, bool OPEN = false, bool SEAM = false>
 static __device__ __forceinline__ void sweep_pairs_nib(const Rows2Ctx& c, const PhiloxKeys& K, int tr_first, int tr_end, int step_rows, int oct,
                                                        uint32_t cq) {
     const char* const ps0 = reinterpret_cast<const char*>(c.Ps);
@@ -350,8 +359,10 @@ static __device__ __forceinline__ void sweep_pairs_nib(const Rows2Ctx& c, const 
         const u32x4 w0 = philox_vk(cq, (uint32_t)rga, c.hs, c.tag_hi, K);
         const u32x4 w1 = philox_vk(cq, (uint32_t)rgb, c.hs, c.tag_hi, K);
         __builtin_amdgcn_sched_barrier(0);
-        const uint32_t Sa = P0 ? nib_shift_next(R1, A0) : nib_shift_prev(R1, A0);
-        const uint32_t Sb = P0 ? nib_shift_prev(R2, A1) : nib_shift_next(R2, A1);
+        const uint32_t Sa = SEAM ? (P0 ? nib_shift_next_seam(R1, A0, c.sh_next) : nib_shift_prev_seam(R1, A0, c.sh_prev))
+                                 : (P0 ? nib_shift_next(R1, A0) : nib_shift_prev(R1, A0));
+        const uint32_t Sb = SEAM ? (P0 ? nib_shift_prev_seam(R2, A1, c.sh_prev) : nib_shift_next_seam(R2, A1, c.sh_next))
+                                 : (P0 ? nib_shift_prev(R2, A1) : nib_shift_next(R2, A1));
         const uint32_t mid = R1 + R2;  // shared by both rows' vertical + centre sums
         const uint32_t cnt0 = R0 + mid + Sa, cnt1 = R3 + mid + Sb;
         const uint32_t cnt0l = cnt0 & 0x0F0F0F0Fu, cnt0h = (cnt0 >> 4) & 0x0F0F0F0Fu;
@@ -380,6 +391,11 @@ static __device__ __forceinline__ void sweep_pairs_nib(const Rows2Ctx& c, const 
             const uint64_t ma = P0 ? c.vm_o : c.vm_e, mb = P0 ? c.vm_e : c.vm_o;
             n0 = (rga < 0 || rga > c.last_row) ? 0u : (n0 & ((uint32_t)ma | ((uint32_t)(ma >> 32) << 4)));
             n1 = (rgb < 0 || rgb > c.last_row) ? 0u : (n1 & ((uint32_t)mb | ((uint32_t)(mb >> 32) << 4)));
+        }
+        if (SEAM) {  // the sites the last octet does not have stay empty
+            const uint32_t m = (uint32_t)c.vm_e | ((uint32_t)(c.vm_e >> 32) << 4);
+            n0 &= m;
+            n1 &= m;
         }
         *reinterpret_cast<uint32_t*>(pd) = n0;
         *reinterpret_cast<uint32_t*>(pd + NO * 4) = n1;
@@ -533,8 +549,10 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
     // periodic lattice of ragged width: v sites per colour in the last octet of a row (cols is even: the same for both)
     const int v_last = (p.cols >> 1) & 7;
     const bool ragged = !OPEN && v_last != 0;
-    c.sh_next = (ragged && cqi == p.nchunks - 1) ? 8 * (v_last - 1) : 56;
-    c.sh_prev = (ragged && cqi == 0) ? 8 * (v_last - 1) : 56;
+    const int seam_site = v_last - 1;  // the site of the ragged octet that is followed by site 0 of octet 0
+    const int seam_pos = NIB ? 8 * (seam_site & 3) + 4 * (seam_site >> 2) : 8 * seam_site, last_pos = NIB ? 28 : 56;
+    c.sh_next = (ragged && cqi == p.nchunks - 1) ? seam_pos : last_pos;
+    c.sh_prev = (ragged && cqi == 0) ? seam_pos : last_pos;
     // does this workgroup's window (octets q0 - 1 .. q0 + WO of the periodic extension) hold the ragged octet or octet 0?
     int w0 = (q0 - 1) % p.nchunks;
     if (w0 < 0) w0 += p.nchunks;
@@ -697,6 +715,9 @@ static __device__ __forceinline__ void tile_body(const TiledParams& p, const int
         if (NIB && OPEN) {
             if (par0) sweep_pairs_nib<NO, 1, false, true>(c, K, tr_first, tr_end, step, oc, cqq);
             else sweep_pairs_nib<NO, 0, false, true>(c, K, tr_first, tr_end, step, oc, cqq);
+        } else if (NIB && seam) {
+            if (par0) sweep_pairs_nib<NO, 1, true, false, true>(c, K, tr_first, tr_end, step, oc, cqq);
+            else sweep_pairs_nib<NO, 0, true, false, true>(c, K, tr_first, tr_end, step, oc, cqq);
         } else if (NIB) {
             if (edge) {
                 if (par0) sweep_pairs_nib<NO, 1, true>(c, K, tr_first, tr_end, step, oc, cqq);
@@ -867,8 +888,7 @@ int ragged_shift(const tsu_ising2d* L, int WO) {
     return -1;
 }
 
-// Tile-resident runs of whole periodic lattices of ANY even height and width (flexible cut; nibble planes for widths that are a
-// multiple of 16 only): the rows are
+// Tile-resident runs of whole lattices of any shape (flexible cut; periodic ones need even height and width): the rows are
 // cut into tiles_y tile rows of (nearly) equal even heights and the last tile column may hold fewer octets than the others, so
 // the lattice need not divide into whole tiles.  As many tile rows as the chip has room for (every tile needs its own
 // workgroup; more tiles = shorter tiles = a shorter generation), the tile shape by the generation-time model of pick_variant.
@@ -881,7 +901,6 @@ int flex_plan(const tsu_ising2d* L, int v, int* v_out, int* hmax_out, double* t_
     }
     if (!flexible || L->ghost != 0 || L->total_rows != L->rows) return 0;
     if (L->periodic && ((L->cols & 1) || (L->rows & 1))) return 0;  // (odd periodic lattices are not bipartite: generic kernel)
-    const bool ragged = L->cols % 16 != 0;  // the wrap falls inside the last octet: byte planes only (SEAM form), tiling shifted by ragged_shift
     static int use_nib = -1;
     if (use_nib < 0) {
         const char* e = getenv("TSU_K1_NIBBLE");
@@ -907,7 +926,7 @@ int flex_plan(const tsu_ising2d* L, int v, int* v_out, int* hmax_out, double* t_
     for (int ci = 0; ci < (int)(sizeof(cand) / sizeof(cand[0])); ++ci) {
         if (v >= 0 && cand[ci] != v) continue;
         const TileVariant& c = kVariants[cand[ci]];
-        if (!(L->periodic ? c.resident : c.resident_open) || (c.nib && (!use_nib || (L->periodic && ragged))) || 2 * nch < c.WO || ragged_shift(L, c.WO) < 0) continue;
+        if (!(L->periodic ? c.resident : c.resident_open) || (c.nib && !use_nib) || 2 * nch < c.WO || ragged_shift(L, c.WO) < 0) continue;
         // (an open lattice may have an odd number of rows: the cut is made over rows + 1, the last tile row holds one row less)
         const int tiles_x = (nch + c.WO - 1) / c.WO, half = (L->rows + 1) / 2;
         int tiles_y = cus / tiles_x;
@@ -964,8 +983,8 @@ TilePlan tile_plan(const tsu_ising2d* L) {
             const char* e = getenv("TSU_K1_NIBBLE");
             use_nib = e ? atoi(e) : 1;
         }
-        // (open lattices: any width -- no wrap, the ragged last octet is masked like every site beyond the edge)
-        const bool nib_ok = use_nib && (L->periodic ? L->cols % 16 == 0 : true) && L->ghost == 0 && L->total_rows == L->rows;
+        // (any width: an open lattice's ragged last octet is masked like every site beyond the edge, a periodic one's takes the SEAM form)
+        const bool nib_ok = use_nib && L->ghost == 0 && L->total_rows == L->rows;
         if (nib_ok && n128 > 2 * cus) {
             const int nch_ = (L->cols + 15) / 16;
             const long long n512 = (long long)(L->rows / 512) * (nch_ / 32);
