@@ -780,10 +780,12 @@ int tsu_ising2d_sweep_batch(tsu_ising2d* const* lats, int n_lats, int n_sweeps, 
         // Tile-resident launches wait inside the kernel for all of their workgroups: never have more of them in flight
         // than fit the chip together (one workgroup per CU counted), or two half-placed grids could wait for each other.
         int max_tiles = 0;
+        ctx->in_batch = 1;  // (the tile plan of a lattice in a batch differs from that of a lattice on its own: see tile_plan)
         for (int i = 0; i < n_lats; ++i) {
             const int t = tsu_ising2d_tiled_tiles(lats[i]);
             if (t > max_tiles) max_tiles = t;
         }
+        ctx->in_batch = 0;
         int used = n_lats < ctx->pool_n ? n_lats : ctx->pool_n;
         if (max_tiles > 0) {
             const int fit = ctx->cus / max_tiles;

@@ -1031,7 +1031,12 @@ TilePlan tile_plan(const tsu_ising2d* L) {
         double t_flex = 0;
         const int fty = forced ? (divides ? 0 : flex_plan(L, v, &fv, &fh, &t_flex)) : flex_plan(L, -1, &fv, &fh, &t_flex);
         bool take = fty > 0 && !standard_resident;
-        if (fty > 0 && standard_resident && !forced && per_cu == 1) {
+        // a batch of lattices (a temperature scan on side streams) wants many lattices in flight, not the shortest generation of
+        // one: lattices that leave half the chip to the others keep the tuned, compact shapes (32 temperatures at 1024^2: 120 ms;
+        // with every lattice cut into 256 tiles 182 ms)
+        const bool compact = L->ctx->in_batch && 2 * nt <= cus;
+        if (compact) take = false;
+        if (fty > 0 && standard_resident && !forced && per_cu == 1 && !compact) {
             const int pairs = (c.H + 4 * 8 - 2) / 2, waves = (pairs * (c.WO + 2) + 63) / 64;
             const double t_std = 16.0 * (0.25 + (c.nib ? 1.06 : 1.0) * 0.225 * ((waves + 3) / 4)) + 4.3;
             take = t_flex < 0.97 * t_std;
