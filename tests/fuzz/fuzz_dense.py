@@ -14,6 +14,8 @@ for case in range(int(os.environ.get("FUZZ_CASES", "30"))):
         n = random.randint(129, 640)
     if os.environ.get("FUZZ_PIPE"):  # the pipeline kernel: N a multiple of 4 from 1024, one / two / three superblocks
         n = 4 * random.randint(256, 2300)
+    if os.environ.get("FUZZ_PIPE_LOW"):  # the pipeline kernel just above the one-workgroup kernel's range: a single short superblock
+        n = 4 * random.randint(113, 300)
     f32 = random.random() < 0.5
     sym = random.random() < 0.7
     T = random.choice([0.1, 0.5, 1.0, 3.0])
@@ -22,7 +24,7 @@ for case in range(int(os.environ.get("FUZZ_CASES", "30"))):
     J = rng.standard_normal((n, n)) / max(1.0, np.sqrt(n)) * random.choice([0.3, 1.0, 3.0])
     if sym:
         J = (J + J.T) / 2
-    if (os.environ.get("FUZZ_SMALL") or os.environ.get("FUZZ_MID") or os.environ.get("FUZZ_PIPE")) and random.random() < 0.3:  # ferromagnet / antiferromagnet: long dependency chains
+    if (os.environ.get("FUZZ_SMALL") or os.environ.get("FUZZ_MID") or os.environ.get("FUZZ_PIPE") or os.environ.get("FUZZ_PIPE_LOW")) and random.random() < 0.3:  # ferromagnet / antiferromagnet: long dependency chains
         J = np.full((n, n), random.choice([1.0, -1.0, 0.25]) * random.choice([1.0, 1.0 / max(1, n)]))
         np.fill_diagonal(J, 0.0)
     if f32:

@@ -19,7 +19,8 @@ def _system(n, seed, f64=False, bias=True):
     return (J.astype(np.float64) if f64 else J), b, rng.integers(0, 2, size=n).astype(np.int8)
 
 
-@pytest.mark.parametrize("n,T,f64", [(1024, 1.0, False), (4096, 1.0, False), (4096, 1.0, True), (5000, 0.7, False), (6144, 1.0, False),
+@pytest.mark.parametrize("n,T,f64", [(452, 1.0, True), (580, 0.6, False), (768, 1.0, False), (1000, 2.0, True), (1020, 1.0, False), (1024, 1.0, False),
+                                     (2048, 0.8, False), (2052, 1.0, True), (4096, 1.0, False), (4096, 1.0, True), (5000, 0.7, False), (6144, 1.0, False),
                                      (8192, 1.0, False), (8196, 1.0, False), (9000, 1.3, True), (12288, 1.0, False), (12292, 0.4, False)])
 def test_pipeline_sweeps_match_oracle(n, T, f64):
     from tsu import _hip

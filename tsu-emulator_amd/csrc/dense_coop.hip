@@ -824,7 +824,13 @@ static int pipe_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint3
     // which had won up to n = 12288 half-way through its development, loses everywhere now
     const int sb = (sb_env == 2048 || sb_env == 4096 || sb_env == 8192) ? sb_env : (n <= 2048 ? 2048 : 4096);
     const int ns = sb / 256;
-    if (!use_pipe || n > CO_MAX_N || n < 1024 || grid < 2 * ns) return TSU_OK;
+    static int pipe_min = -1;
+    if (pipe_min < 0) {
+        const char* e = getenv("TSU_K2_PIPE_MIN");
+        pipe_min = e ? atoi(e) : 452;  // just above the one-workgroup kernel (k2_wg: 576 fp32 / 448 fp64 sites): 45-50 us per sweep at
+                                       // n = 580 .. 1020 against 50-62 us on the barrier kernel
+    }
+    if (!use_pipe || n > CO_MAX_N || n < pipe_min || grid < 2 * ns) return TSU_OK;
     if ((long long)(grid - ns) * (CO_THREADS / 64) * PP_MAXR < n) return TSU_OK;
     if (n % 4) return TSU_OK;  // state / flips travel as dwords
     const bool vec = (n % JVec<TJ>::W) == 0;
