@@ -8,7 +8,7 @@
 // Paths, all with the same results (dispatch in tsu_dense_sweep), natural order by system size:
 //   * k2_small (n <= 192 fp32 J / 128 fp64 J): a whole call (or sample_boltzmann run, annealing schedule, tempering
 //     ladder) in one launch of a single wave, J in LDS;
-//   * k2_wg (n <= 576 / 448): one workgroup, a thread per site, J^T columns from L2;
+//   * k2_wg (n <= 528 / 448): one workgroup, a thread per site, J^T columns from L2;
 //   * larger: dense_coop.hip -- the whole call in one cooperative launch (superblock fixed point);
 //   * the same fixed point with one launch per iteration (k2_sb_iter / k2_sb_finish) when a cooperative launch is
 //     not available;
@@ -319,7 +319,8 @@ __global__ __launch_bounds__(64) void k2_small_replicas(const TJ* __restrict__ J
 }
 
 // largest n on the one-workgroup kernel: the measured crossover against the cooperative kernel
-// (tools/dense_mid_times.py): fp32 J ~600 sites, fp64 J ~470; TSU_K2_WG=n overrides (0: never)
+// (tools/dense_mid_times.py): fp32 J ~600 sites, fp64 J ~470 against the barrier kernel; against the pipeline (which now starts
+// at n = 452 with a streamer grid sized to the system) fp32 ~530: n = 500 30 us here / 34 there, n = 576 41 / 36; TSU_K2_WG=n overrides (0: never)
 static bool k2wg_takes(const tsu_dense* d) {
     static int use_wg = -2;
     if (use_wg == -2) {
@@ -327,7 +328,7 @@ static bool k2wg_takes(const tsu_dense* d) {
         use_wg = e ? atoi(e) : -1;
         if (use_wg > 1024) use_wg = 1024;
     }
-    return d->n <= (use_wg >= 0 ? use_wg : (d->dtype == TSU_DTYPE_F64 ? 448 : 576));
+    return d->n <= (use_wg >= 0 ? use_wg : (d->dtype == TSU_DTYPE_F64 ? 448 : 528));
 }
 
 // slots per lane the one-wave kernels need for this system, 0 if it does not fit one CU's LDS (TSU_K2_WAVE=0: at most 1)

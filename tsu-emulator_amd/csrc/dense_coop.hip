@@ -814,7 +814,14 @@ static int pipe_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint3
         const char* e = getenv("TSU_K2_PIPE");
         use_pipe = e ? atoi(e) : 1;
     }
-    const int grid = ctx->cus;
+    int grid = ctx->cus;
+    // small systems: fewer streamer workgroups (every workgroup takes part in the hand-off counters, and a system of a few hundred
+    // rows has no work for 4000 waves); from 2048 rows up every CU streams.  TSU_K2_PIPE_WG_PER_1024 = workgroups per 1024 rows (0: every CU)
+    static int grid_env = -1;
+    if (grid_env < 0) {
+        const char* e = getenv("TSU_K2_PIPE_WG_PER_1024");
+        grid_env = e ? atoi(e) : 128;  // measured (n = 580 / 1024: 36 / 42 us per sweep; with every CU 46 / 49, with 64 per 1024 rows 40 / 44)
+    }
     static int sb_env = -1;
     if (sb_env < 0) {
         const char* e = getenv("TSU_K2_PIPE_SB");
@@ -824,6 +831,10 @@ static int pipe_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint3
     // which had won up to n = 12288 half-way through its development, loses everywhere now
     const int sb = (sb_env == 2048 || sb_env == 4096 || sb_env == 8192) ? sb_env : (n <= 2048 ? 2048 : 4096);
     const int ns = sb / 256;
+    if (grid_env > 0) {
+        const int want = ns + (int)(((long long)n * grid_env + 1023) / 1024);
+        if (want < grid) grid = want;
+    }
     static int pipe_min = -1;
     if (pipe_min < 0) {
         const char* e = getenv("TSU_K2_PIPE_MIN");
