@@ -412,9 +412,14 @@ __global__ __launch_bounds__(CO_THREADS) void k2_coop(CoopParams P) {
 #define PP_TEAMS 4                // 64-row groups per solver workgroup
 #define PP_GRAN_MAX (PP_SB_MAX / 32)
 #define PP_MAXR 24                // rows one streamer wave may own
-#define PB_C1 BAR_CNT(0)          // counter words on pages of their own (the grid-barrier layout is not used here)
-#define PB_SOLVED BAR_CNT(1)
-#define PB_T BAR_CNT(2)
+#define PB_SOLVED BAR_CNT(1)       // counter words on pages of their own (the grid-barrier layout is not used here)
+// C1 and T count ~240 streamer workgroups each: sharded eight ways by workgroup index (one atomic per ~12 ns on ONE word would put
+// 3 us of arrivals in front of every wait; the guide's "fanin" row), the waiter's first eight lanes poll one shard each
+#ifndef PP_SHARDS
+#define PP_SHARDS 8
+#endif
+#define PB_C1(x) ((2 + (x)) * BAR_PAGE)              // pages 2 .. 2 + PP_SHARDS - 1
+#define PB_T(x) ((2 + PP_SHARDS + (x)) * BAR_PAGE)   // the next PP_SHARDS pages (PP_SHARDS <= 16: the error words sit on page 35)
 #define PP_BATCH 16               // J^T elements in flight per lane in the gather
 #ifndef PP_U
 #define PP_U 8                    // 16-byte loads in flight per lane in the streamers' strip passes
@@ -443,6 +448,36 @@ struct PipeParams {
 // one lane polls, the workgroup follows its verdict
 static __device__ __forceinline__ bool wg_wait(unsigned* bar, int word, unsigned target, int* s_ok) {
     if (threadIdx.x == 0) *s_ok = bar_wait(bar, &bar[word], target) ? 1 : 0;
+    __syncthreads();
+    const bool ok = *s_ok != 0;
+    __syncthreads();
+    return ok;
+}
+
+// wait until every streamer workgroup (indices first_wg .. n_wg - 1 of the grid) has arrived `events` times at the sharded counter
+// whose shard x lives at word0 + x * stride: lanes 0 .. 7 of the workgroup's first wave poll one shard each
+static __device__ __forceinline__ bool wg_wait_sharded(unsigned* bar, int word0, int stride, unsigned events, int first_wg, int n_wg, int* s_ok) {
+    if (threadIdx.x < 64) {
+        const int x = threadIdx.x & (PP_SHARDS - 1);
+        const int hi = n_wg - 1 - x >= 0 ? (n_wg - 1 - x) / PP_SHARDS + 1 : 0, lo = first_wg - 1 - x >= 0 ? (first_wg - 1 - x) / PP_SHARDS + 1 : 0;
+        const unsigned target = events * (unsigned)(hi - lo);
+        const unsigned* word = bar + word0 + x * stride;
+        bool ok = true;
+        const long long t0 = wall_clock64();
+        for (unsigned spins = 0;; ++spins) {
+            const bool there = threadIdx.x >= PP_SHARDS || __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
+            if (__ballot(!there) == 0ull) break;
+            if ((spins & 63u) == 63u) {
+                if (__hip_atomic_load(&bar[BAR_ERR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || wall_clock64() - t0 > CO_TIMEOUT) {
+                    __hip_atomic_store(&bar[BAR_ERR], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = false;
+                    break;
+                }
+            }
+        }
+        const bool all_ok = __ballot(!ok) == 0ull;  // (the lanes leave the loop one by one on an error: the wave is whole again here)
+        if (threadIdx.x == 0) *s_ok = all_ok ? 1 : 0;
+    }
     __syncthreads();
     const bool ok = *s_ok != 0;
     __syncthreads();
@@ -497,7 +532,7 @@ __global__ __launch_bounds__(CO_THREADS) void k2_pipe(PipeParams P) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) {
                 const unsigned a = atomicAdd(&s_c1, 1u);
-                if (a + 1 == ev * (CO_THREADS / 64)) __hip_atomic_fetch_add(&P.bar[PB_C1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a + 1 == ev * (CO_THREADS / 64)) __hip_atomic_fetch_add(&P.bar[PB_C1(blockIdx.x & (PP_SHARDS - 1))], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         };
         // ---- T: once EVERY row of superblock [q0, q1) has its field, its first guesses d0_i = decide(f_i) - s_i are known --
@@ -516,7 +551,7 @@ __global__ __launch_bounds__(CO_THREADS) void k2_pipe(PipeParams P) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) {
                 const unsigned a = atomicAdd(&s_t, 1u);
-                if (a + 1 == tev * (CO_THREADS / 64)) __hip_atomic_fetch_add(&P.bar[PB_T], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a + 1 == tev * (CO_THREADS / 64)) __hip_atomic_fetch_add(&P.bar[PB_T(blockIdx.x & (PP_SHARDS - 1))], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             return true;
         };
@@ -551,7 +586,7 @@ __global__ __launch_bounds__(CO_THREADS) void k2_pipe(PipeParams P) {
                     }
                 }
                 signal_c1();
-                if (!wg_wait(P.bar, PB_C1, ev * n_stream, &s_ok)) return;
+                if (!wg_wait_sharded(P.bar, PB_C1(0), BAR_PAGE, ev, NS, (int)gridDim.x, &s_ok)) return;
                 if (!t_pass(0, SB < n ? SB : n)) return;
                 __syncthreads();  // wl is restaged below
             }
@@ -585,7 +620,7 @@ __global__ __launch_bounds__(CO_THREADS) void k2_pipe(PipeParams P) {
                 // nothing else is started until EVERY workgroup's priority rows are through: other loads would queue in
                 // front of the stragglers' (a few waves own two priority rows), and the solvers' start is the critical path
                 if (q1 > q0) {
-                    if (!wg_wait(P.bar, PB_C1, ev * n_stream, &s_ok)) return;
+                    if (!wg_wait_sharded(P.bar, PB_C1(0), BAR_PAGE, ev, NS, (int)gridDim.x, &s_ok)) return;
                     if (!t_pass(q0, q1)) return;
                 }
                 ST_MARK(2);
@@ -635,7 +670,7 @@ __global__ __launch_bounds__(CO_THREADS) void k2_pipe(PipeParams P) {
             // my logit: before the fields arrive
             const double lg = active ? co_logit((uint32_t)i, uni, t, P.tag, P.k0, P.k1) : 0.0;
             PP_MARK(3);
-            if (!wg_wait(P.bar, PB_C1, ev * n_stream, &s_ok)) return;
+            if (!wg_wait_sharded(P.bar, PB_C1(0), BAR_PAGE, ev, NS, (int)gridDim.x, &s_ok)) return;
             PP_MARK(0);
             // state of the superblock at the start of the sweep.  Read AFTER the fields have arrived: with a single superblock
             // its rows were committed by the other solver workgroups just before (the previous sweep's solve), and only the
@@ -718,7 +753,7 @@ __global__ __launch_bounds__(CO_THREADS) void k2_pipe(PipeParams P) {
                 if (k == 0) {
                     // iteration 0 -> 1: all first guesses at once = the streamers' triangular pass
                     ++tev;
-                    if (!wg_wait(P.bar, PB_T, tev * n_stream, &s_ok)) return;
+                    if (!wg_wait_sharded(P.bar, PB_T(0), BAR_PAGE, tev, NS, (int)gridDim.x, &s_ok)) return;
                     if (owner) {
                         corr = active ? ld(P.corr + i) : 0.0;
                         flipped = active && co_decide(fi + corr, lg, T, invT, (uint32_t)i, uni, t, P.tag, P.k0, P.k1) != si;
