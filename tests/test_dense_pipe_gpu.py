@@ -62,3 +62,47 @@ def test_pipeline_replays_numpy_uniforms():
     want = ora.c_dense_sweep_replay(s0.astype(np.int64), J, b, 0.9, u)
     np.testing.assert_array_equal(d.get_state(), want.astype(np.int8))
     d.close()
+
+
+@pytest.mark.parametrize("n,f64", [(1024, False), (2052, True), (4096, False), (6144, False)])
+def test_fields_handed_from_call_to_call_give_the_same_trajectory_and_energy(n, f64):
+    """Loops of short calls (annealing, tempering): from the second consecutive call on the pipeline keeps the fields of the final
+    state and the next call (and tsu_dense_energy) starts from them instead of streaming J again.  Every call's state must equal
+    the oracle's, the energies the oracle's within rounding, a set_state in between must drop the kept fields."""
+    from tsu import _hip
+    J, b, s0 = _system(n, 3 * n + 1, f64)
+    J64 = np.asarray(J, dtype=np.float64)
+    d = _hip.DenseSystem(J, b, _hip.DTYPE_F64 if f64 else _hip.DTYPE_F32)
+    d.set_state(s0)
+    want, sw = s0, 5
+    calls = [(1, 1.0), (1, 0.9), (3, 0.8), (1, 0.7), (2, 1.3), (1, 0.6), (1, 0.5)]
+    for k, (ns, T) in enumerate(calls):
+        d.sweep(T, ns, seed=11, sweep0=sw)
+        want = ora.dense_sweep_philox(want, J64, b, T, ns, 11, sweep0=sw)
+        sw += ns
+        np.testing.assert_array_equal(d.get_state(), want, err_msg=f"call {k}")
+        e = d.energy()
+        assert abs(e - ora.ref_compute_energy(want.astype(np.int64), J64, b)) <= 1e-9 * n, k
+        if k == 4:  # another state: the kept fields are not its fields
+            want = 1 - want
+            d.set_state(want.astype(np.int8))
+            assert abs(d.energy() - ora.ref_compute_energy(want.astype(np.int64), J64, b)) <= 1e-9 * n
+    d.close()
+
+
+def test_kept_fields_are_recomputed_every_64_sweeps_across_calls():
+    # 70 one-sweep calls cross the refresh period of the incremental fields (CO_REFRESH = 64 sweeps, counted across calls)
+    from tsu import _hip
+    n = 1024
+    J, b, s0 = _system(n, 77)
+    J64 = np.asarray(J, dtype=np.float64)
+    d = _hip.DenseSystem(J, b, _hip.DTYPE_F32)
+    d.set_state(s0)
+    want = s0
+    for k in range(70):
+        d.sweep(1.0, 1, seed=5, sweep0=k)
+        want = ora.dense_sweep_philox(want, J64, b, 1.0, 1, 5, sweep0=k)
+        if k % 9 == 0 or k >= 60:
+            np.testing.assert_array_equal(d.get_state(), want, err_msg=f"call {k}")
+    np.testing.assert_array_equal(d.get_state(), want)
+    d.close()

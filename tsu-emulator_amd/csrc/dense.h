@@ -42,6 +42,12 @@ struct tsu_dense {
     int co_disabled;    // cooperative launch unavailable or failed once: use the multi-launch path
     unsigned long long* pp_masks;  // k2_pipe: flip-mask granules of the solver teams
     int pp_failed;      // k2_pipe ran and left the state half updated: the caller restores it, later calls skip the pipeline
+    // k2_pipe hands the fields f = J s + b from call to call (a loop of one-sweep calls -- annealing, tempering -- would otherwise
+    // stream J once more per call to rebuild them, and tsu_dense_energy once more again):
+    double* co_fields;  // [n] fields of the state as the last pipeline call left it
+    int fields_valid;   // co_fields belongs to d->state (cleared by everything else that writes the state)
+    int since_refresh;  // sweeps since the fields were last computed from scratch (CO_REFRESH bounds the drift across calls too)
+    int pipe_streak;    // consecutive pipeline calls on this state: the second one starts to keep the fields
 };
 
 

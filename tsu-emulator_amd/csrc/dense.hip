@@ -877,6 +877,7 @@ int tsu_dense_destroy(tsu_dense* d) {
     if (d->co_counts) (void)hipFree(d->co_counts);
     if (d->co_bar) (void)hipFree(d->co_bar);
     if (d->pp_masks) (void)hipFree(d->pp_masks);
+    if (d->co_fields) (void)hipFree(d->co_fields);
     delete d;
     return TSU_OK;
 }
@@ -888,6 +889,8 @@ int tsu_dense_set_state(tsu_dense* d, const int8_t* bits_host) {
     for (int i = 0; i < d->n; ++i) TSU_REQUIRE(d->ctx, bits_host[i] == 0 || bits_host[i] == 1, "dense_set_state: state must be 0/1");
     TSU_HIP_TRY(d->ctx, hipMemcpyAsync(d->state, bits_host, (size_t)d->n, hipMemcpyHostToDevice, d->ctx->stream));
     TSU_HIP_TRY(d->ctx, hipStreamSynchronize(d->ctx->stream));
+    d->fields_valid = 0;  // the pipeline's kept fields belong to the old state
+    d->pipe_streak = 0;
     return TSU_OK;
 }
 
@@ -974,6 +977,10 @@ int tsu_dense_sweep(tsu_dense* d, double T, int n_sweeps, const int64_t* order, 
     // natural order: the whole call in one cooperative launch; if that is unavailable, the same fixed point with one
     // launch per iteration; the block-by-block path serves custom orders, tiny systems and a superblock that did not
     // converge within its iteration slots
+    if (!(use_coop && !d->co_disabled && !order && d->n >= 2 * DB)) {  // another path writes the state: the pipeline's kept fields go stale
+        d->fields_valid = 0;
+        d->pipe_streak = 0;
+    }
     if (use_coop && !d->co_disabled && !order && d->n >= 2 * DB) {
         TSU_HIP_TRY(ctx, hipMemcpyAsync(d->backup, d->state, (size_t)d->n, hipMemcpyDeviceToDevice, ctx->stream));
         int done = 0;
@@ -1162,15 +1169,22 @@ int tsu_dense_energy(tsu_dense* d, double* energy) {
     if (!d) return TSU_E_INVALID;
     tsu_ctx* ctx = d->ctx;
     TSU_REQUIRE(ctx, energy != nullptr, "dense_energy: NULL");
-    unsigned mv_grid = (unsigned)(((size_t)d->n * 64 + 255) / 256);
-    if (d->dtype == TSU_DTYPE_F64)
-        k2_matvec<double><<<mv_grid, 256, 0, ctx->stream>>>((const double*)d->J, d->state, d->bias, d->field, d->n);
-    else
-        k2_matvec<float><<<mv_grid, 256, 0, ctx->stream>>>((const float*)d->J, d->state, d->bias, d->field, d->n);
+    // the fields f = J s + b: those the pipeline kept for exactly this state (a loop of sweep + energy calls then streams J once per
+    // step instead of three times), or one pass over J
+    const double* fields = d->field;
+    if (d->fields_valid && d->co_fields) {
+        fields = d->co_fields;
+    } else {
+        unsigned mv_grid = (unsigned)(((size_t)d->n * 64 + 255) / 256);
+        if (d->dtype == TSU_DTYPE_F64)
+            k2_matvec<double><<<mv_grid, 256, 0, ctx->stream>>>((const double*)d->J, d->state, d->bias, d->field, d->n);
+        else
+            k2_matvec<float><<<mv_grid, 256, 0, ctx->stream>>>((const float*)d->J, d->state, d->bias, d->field, d->n);
+    }
     TSU_HIP_TRY(ctx, hipMemsetAsync(d->d_energy, 0, 8, ctx->stream));
     int blocks = (d->n + 255) / 256;
     if (blocks > 1024) blocks = 1024;
-    k2_energy<<<blocks, 256, 0, ctx->stream>>>(d->field, d->state, d->bias, d->d_energy, d->n);
+    k2_energy<<<blocks, 256, 0, ctx->stream>>>(fields, d->state, d->bias, d->d_energy, d->n);
     TSU_HIP_TRY(ctx, hipGetLastError());
     TSU_HIP_TRY(ctx, hipMemcpyAsync(energy, d->d_energy, 8, hipMemcpyDeviceToHost, ctx->stream));
     TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -441,6 +441,10 @@ struct PipeParams {
     int n, n_sweeps;
     double T;
     uint32_t sweep0, tag, k0, k1;
+    double* fields_all;  // [n] fields of every row, kept from call to call (see dense.h)
+    int resume;          // fields_all holds the fields of the state the call starts from: no pass over J to rebuild them
+    int persist;         // leave the fields of the final state in fields_all (the call's last sweep then updates every row)
+    int refresh_off;     // sweeps since the fields were last computed from scratch, at the start of the call
     unsigned long long* timeline;  // TSU_K2_VERBOSE=2: solver workgroup 0, ticks in [wait C1, poll, gather+decide, commit], [4] iterations, [5] toggles;
                                    // first streamer workgroup, wave 0: [6] wait SOLVED, [7] stage, [8] priority rows + signal, [9] other rows
 };
@@ -565,19 +569,25 @@ __global__ __launch_bounds__(CO_THREADS) void k2_pipe(PipeParams P) {
         stl_last = now_;                                    \
     }
         for (int sw = 0; sw < P.n_sweeps; ++sw) {
-            const bool fresh = (sw % CO_REFRESH) == 0;
-            const bool next_incremental = sw + 1 < P.n_sweeps && ((sw + 1) % CO_REFRESH) != 0;
-            if (fresh) {
-                // fields from scratch (first sweep of a call and every CO_REFRESH sweeps): needs the complete state
+            // a sweep starts from complete fields: computed from scratch every CO_REFRESH sweeps (counted across calls) and at the
+            // start of a call -- unless the previous call left them (resume) -- or handed on by the previous sweep
+            const bool start_phase = sw == 0 || ((sw + P.refresh_off) % CO_REFRESH) == 0;
+            const bool resume_now = sw == 0 && P.resume;
+            const bool next_incremental = sw + 1 < P.n_sweeps && ((sw + 1 + P.refresh_off) % CO_REFRESH) != 0;  // priority rows for the next sweep
+            const bool keep_all = next_incremental || (sw + 1 == P.n_sweeps && P.persist);                      // every row's field stays current
+            if (start_phase) {
+                // (from scratch: needs the complete state)
                 if (!wg_wait(P.bar, PB_SOLVED, seq * NS, &s_ok)) return;
-                stage_weights(P.state, 0, n, wl);
-                __syncthreads();
+                if (!resume_now) {
+                    stage_weights(P.state, 0, n, wl);
+                    __syncthreads();
+                }
                 ++ev;
                 int m = 0;
                 for (int r = ws; r < n; r += W, ++m) {
-                    const double acc = wave_dot<TJ, VEC>(J + (size_t)r * n, wl, 0, 0, n, lane);
+                    const double acc = resume_now ? 0.0 : wave_dot<TJ, VEC>(J + (size_t)r * n, wl, 0, 0, n, lane);
                     if (lane == 0) {
-                        const double F = acc + (P.bias ? P.bias[r] : 0.0);
+                        const double F = resume_now ? P.fields_all[r] : acc + (P.bias ? P.bias[r] : 0.0);
                         s_f[wv][m] = F;
                         if (r < SB) {
                             st(P.f + r, F);
@@ -604,7 +614,7 @@ __global__ __launch_bounds__(CO_THREADS) void k2_pipe(PipeParams P) {
                 // are handed on; rows below row_lo are not needed again in this sweep and start afresh in the next
                 const bool last = sb == nsb - 1;
                 const int q0 = last ? 0 : pe, q1 = last ? (next_incremental ? (SB < n ? SB : n) : 0) : (pe + SB < n ? pe + SB : n);
-                const int row_lo = next_incremental ? 0 : pe;
+                const int row_lo = keep_all ? 0 : pe;
                 int m = 0;
                 for (int r = ws; r < n; r += W, ++m) {
                     if (r < q0 || r >= q1) continue;
@@ -632,6 +642,11 @@ __global__ __launch_bounds__(CO_THREADS) void k2_pipe(PipeParams P) {
                 }
                 __syncthreads();  // every wave is done with wl before it is restaged
             }
+        }
+        if (P.persist) {  // the fields of the final state, for the next call
+            int m = 0;
+            for (int r = ws; r < n; r += W, ++m)
+                if (lane == 0) P.fields_all[r] = s_f[wv][m];
         }
         if (stiming)
             for (int x = 0; x < 4; ++x) P.timeline[6 + x] = stl[x];
@@ -662,7 +677,7 @@ __global__ __launch_bounds__(CO_THREADS) void k2_pipe(PipeParams P) {
     for (int sw = 0; sw < P.n_sweeps; ++sw) {
         const uint32_t t = P.sweep0 + (uint32_t)sw;
         const double* uni = P.uniforms ? P.uniforms + (size_t)sw * n : nullptr;
-        if ((sw % CO_REFRESH) == 0) ++ev;
+        if (sw == 0 || ((sw + P.refresh_off) % CO_REFRESH) == 0) ++ev;
         for (int sb = 0; sb < nsb; ++sb) {
             const int p0 = sb * SB, pe = p0 + SB < n ? p0 + SB : n, cnt = pe - p0;
             const int il = 64 * g + lane, i = p0 + il;
@@ -840,7 +855,7 @@ __global__ __launch_bounds__(CO_THREADS) void k2_pipe(PipeParams P) {
 
 template <typename TJ>
 static int pipe_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint32_t sweep0, uint32_t replica, bool have_uni,
-                      int* done) {
+                      int* done, bool fields_were_valid) {
     tsu_ctx* ctx = d->ctx;
     const int n = d->n;
     *done = 0;
@@ -903,6 +918,7 @@ static int pipe_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint3
     if (!d->pp_masks) TSU_HIP_TRY(ctx, hipMalloc(&d->pp_masks, 3 * PP_GRAN_MAX * sizeof(unsigned long long)));
     if (!d->co_corr) TSU_HIP_TRY(ctx, hipMalloc(&d->co_corr, (size_t)n * 8));
     if (!d->co_d0) TSU_HIP_TRY(ctx, hipMalloc(&d->co_d0, (size_t)n));
+    if (!d->co_fields) TSU_HIP_TRY(ctx, hipMalloc(&d->co_fields, (size_t)n * 8));
     TSU_HIP_TRY(ctx, hipMemsetAsync(d->co_bar, 0, BAR_WORDS * sizeof(unsigned), ctx->stream));
     TSU_HIP_TRY(ctx, hipMemsetAsync(d->pp_masks, 0, 3 * PP_GRAN_MAX * sizeof(unsigned long long), ctx->stream));
     PipeParams P;
@@ -924,6 +940,17 @@ static int pipe_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint3
     P.tag = TSU_TAG_DENSE | (replica << 8);
     P.k0 = (uint32_t)seed;
     P.k1 = (uint32_t)(seed >> 32);
+    // fields from call to call: resume when the previous pipeline call left them for exactly this state and no refresh is due;
+    // keep them from the second consecutive call on (a lone call does not pay for rows it would not need again)
+    static int keep_fields = -1;
+    if (keep_fields < 0) {
+        const char* e = getenv("TSU_K2_KEEP_FIELDS");
+        keep_fields = e ? atoi(e) : 1;
+    }
+    P.fields_all = d->co_fields;
+    P.resume = keep_fields && fields_were_valid && (d->since_refresh % CO_REFRESH) != 0 ? 1 : 0;
+    P.refresh_off = P.resume ? d->since_refresh : 0;
+    P.persist = keep_fields && d->pipe_streak >= 1 ? 1 : 0;
     const char* verbose = getenv("TSU_K2_VERBOSE");
     unsigned long long* d_tl = nullptr;
     if (verbose && atoi(verbose) >= 2) {
@@ -967,6 +994,9 @@ static int pipe_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint3
         return TSU_OK;
     }
     *done = 1;
+    d->since_refresh = (P.refresh_off + n_sweeps) % CO_REFRESH;
+    d->fields_valid = P.persist;
+    d->pipe_streak += 1;
     return TSU_OK;
 }
 
@@ -1091,9 +1121,17 @@ int tsu_dense_coop_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, ui
                          int* done) {
     // first choice: the two-role pipeline (in place on d->state); it declines small / odd systems and reports a failed
     // run with *done = 0, in which case the caller has restored the state and the barrier kernel below takes the call
+    // (whatever happens below, the fields kept from the last pipeline call stop being those of d->state; a successful pipeline call
+    // sets the flag again)
+    const bool fields_were_valid = d->fields_valid != 0;
+    const int streak = d->pipe_streak;
+    d->fields_valid = 0;
+    d->pipe_streak = 0;
     if (!d->pp_failed) {
-        const int rc = d->dtype == TSU_DTYPE_F64 ? pipe_sweep<double>(d, T, n_sweeps, seed, sweep0, replica, have_uni, done)
-                                                 : pipe_sweep<float>(d, T, n_sweeps, seed, sweep0, replica, have_uni, done);
+        d->pipe_streak = streak;
+        const int rc = d->dtype == TSU_DTYPE_F64 ? pipe_sweep<double>(d, T, n_sweeps, seed, sweep0, replica, have_uni, done, fields_were_valid)
+                                                 : pipe_sweep<float>(d, T, n_sweeps, seed, sweep0, replica, have_uni, done, fields_were_valid);
+        if (!*done) d->pipe_streak = 0;
         if (rc != TSU_OK || *done) return rc;
         if (d->pp_failed)  // it ran and gave up half way: back to the state at the start of the call (the caller's backup)
             TSU_HIP_TRY(d->ctx, hipMemcpyAsync(d->state, d->backup, (size_t)d->n, hipMemcpyDeviceToDevice, d->ctx->stream));
