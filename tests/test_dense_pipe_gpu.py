@@ -106,3 +106,38 @@ def test_kept_fields_are_recomputed_every_64_sweeps_across_calls():
             np.testing.assert_array_equal(d.get_state(), want, err_msg=f"call {k}")
     np.testing.assert_array_equal(d.get_state(), want)
     d.close()
+
+
+@pytest.mark.parametrize("n,f64", [(600, False), (1024, True), (2052, False), (4100, False)])
+def test_whole_sampling_run_and_annealing_schedule_in_one_pipeline_launch(n, f64):
+    """tsu_dense_sample / tsu_dense_anneal above the one-workgroup kernels: burn-in, the recorded states and a temperature per sweep
+    all inside ONE launch of the pipeline kernel (it used to be one call per recorded state).  Every recorded state == oracle; with
+    replayed uniforms too; a following call continues from the final state."""
+    from tsu import _hip
+    J, b, s0 = _system(n, 7 * n + 3, f64)
+    J64 = np.asarray(J, dtype=np.float64)
+    d = _hip.DenseSystem(J, b, _hip.DTYPE_F64 if f64 else _hip.DTYPE_F32)
+    # sample_boltzmann: 3 burn-in sweeps, then 4 x (2 sweeps, record)
+    d.set_state(s0)
+    got = d.sample(0.9, 3, 2, 4, seed=21, sweep0=10)
+    want = ora.dense_sweep_philox(s0, J64, b, 0.9, 3, 21, sweep0=10)
+    for k in range(4):
+        want = ora.dense_sweep_philox(want, J64, b, 0.9, 2, 21, sweep0=13 + 2 * k)
+        np.testing.assert_array_equal(got[k], want, err_msg=f"sample {k}")
+    np.testing.assert_array_equal(d.get_state(), want)
+    # an annealing schedule: one sweep per temperature, every state recorded; continues from the state above
+    temps = [2.0 * (0.05 / 2.0) ** (k / 9) for k in range(9)]
+    got = d.anneal(temps, seed=22, sweep0=40)
+    for k, T in enumerate(temps):
+        want = ora.dense_sweep_philox(want, J64, b, T, 1, 22, sweep0=40 + k)
+        np.testing.assert_array_equal(got[k], want, err_msg=f"annealing step {k}")
+    # replayed uniforms (the reference's own stream): 2 burn-in + 3 x 1 sweeps
+    rng = np.random.default_rng(5)
+    u = rng.random((5, n))
+    d.set_state(s0)
+    got = d.sample(1.1, 2, 1, 3, replay_uniforms=u)
+    want = ora.c_dense_sweep_replay(s0.astype(np.int64), J64, b, 1.1, u[:2])
+    for k in range(3):
+        want = ora.c_dense_sweep_replay(want, J64, b, 1.1, u[2 + k:3 + k])
+        np.testing.assert_array_equal(got[k], want.astype(np.int8), err_msg=f"replayed sample {k}")
+    d.close()

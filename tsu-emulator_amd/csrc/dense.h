@@ -86,5 +86,7 @@ static __device__ __forceinline__ int dense_decide(double F, double lg, double T
 
 // cooperative single-launch sweep (dense_coop.hip): TSU_OK with *done = 1 when the call was carried out, *done = 0
 // when the path is unavailable or a superblock did not converge (state untouched or restored by the caller)
+int tsu_dense_pipe_run(tsu_dense* d, double T, const double* temps_dev, int n_total, int rec_from, int rec_every, int8_t* samples_dev,
+                       uint64_t seed, uint32_t sweep0, uint32_t replica, bool have_uni, int* done);
 int tsu_dense_coop_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint32_t sweep0, uint32_t replica,
                          bool have_uni, int* done);

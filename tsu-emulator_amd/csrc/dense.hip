@@ -1067,7 +1067,50 @@ static int dense_run(tsu_dense* d, double T, const double* temps, int n_burnin, 
             TSU_HIP_TRY(ctx, k2wg_launch(d, ctx->stream, replay_uniforms ? d->uniforms : nullptr, d->samples, T, temps_dev, n_burnin, n_sweeps,
                                          n_samples, sweep0, tag, (uint32_t)seed, (uint32_t)(seed >> 32), nullptr));
     } else {
-        // larger systems: the sweep paths above, one call per recorded state; samples gathered on the device
+        // larger systems in natural order: the whole run in ONE launch of the pipeline kernel (it records the states itself and takes
+        // a temperature per sweep) -- a loop of calls costs ~60 us per call beside sweeps of 40-100 us at n = 1000-4000
+        static int one_launch = -1;
+        if (one_launch < 0) {
+            const char* e = getenv("TSU_K2_RUN_ONE_LAUNCH");
+            one_launch = e ? atoi(e) : 1;
+        }
+        const size_t ucnt = (size_t)total * n;
+        if (one_launch && !order && total > 0 && !d->co_disabled && n >= 2 * DB && (!replay_uniforms || ucnt * 8 <= ((size_t)1 << 29))) {
+            const double* temps_dev = nullptr;
+            if (temps) {  // (a schedule: n_burnin == 0, n_sweeps == 1, one temperature per recorded state)
+                if (d->temps_cap < (size_t)total) {
+                    if (d->temps) (void)hipFree(d->temps);
+                    d->temps = nullptr;
+                    d->temps_cap = 0;
+                    TSU_HIP_TRY(ctx, hipMalloc(&d->temps, (size_t)total * 8));
+                    d->temps_cap = (size_t)total;
+                }
+                TSU_HIP_TRY(ctx, hipMemcpyAsync(d->temps, temps, (size_t)total * 8, hipMemcpyHostToDevice, ctx->stream));
+                temps_dev = d->temps;
+            }
+            if (replay_uniforms) {
+                if (d->uni_cap < ucnt) {
+                    if (d->uniforms) (void)hipFree(d->uniforms);
+                    d->uniforms = nullptr;
+                    d->uni_cap = 0;
+                    TSU_HIP_TRY(ctx, hipMalloc(&d->uniforms, ucnt * 8));
+                    d->uni_cap = ucnt;
+                }
+                TSU_HIP_TRY(ctx, hipMemcpyAsync(d->uniforms, replay_uniforms, ucnt * 8, hipMemcpyHostToDevice, ctx->stream));
+            }
+            TSU_HIP_TRY(ctx, hipMemcpyAsync(d->backup, d->state, (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+            int done = 0;
+            const int rc1 = tsu_dense_pipe_run(d, T, temps_dev, (int)total, n_burnin, n_sweeps, d->samples, seed, sweep0, replica, replay_uniforms != nullptr,
+                                               &done);
+            if (rc1 != TSU_OK) return rc1;
+            if (done) {
+                if (out_bytes) TSU_HIP_TRY(ctx, hipMemcpyAsync(samples_host, d->samples, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+                TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                return TSU_OK;
+            }
+            TSU_HIP_TRY(ctx, hipMemcpyAsync(d->state, d->backup, (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));  // declined or gave up: the loop below
+        }
+        // otherwise the sweep paths above, one call per recorded state; samples gathered on the device
         // (with a schedule every recorded state is one sweep: n_burnin == 0 and n_sweeps == 1)
         int rc = tsu_dense_sweep(d, T, n_burnin, order, seed, sweep0, replica, replay_uniforms);
         if (rc != TSU_OK) return rc;

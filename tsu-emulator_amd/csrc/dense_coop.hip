@@ -441,6 +441,9 @@ struct PipeParams {
     int n, n_sweeps;
     double T;
     uint32_t sweep0, tag, k0, k1;
+    const double* temps;  // one temperature per sweep of the call (an annealing schedule), or nullptr: T
+    int8_t* samples;      // the state after sweep rec_from + m rec_every (m = 1, 2, ...) goes to samples + (m - 1) n, or nullptr
+    int rec_from, rec_every;
     double* fields_all;  // [n] fields of every row, kept from call to call (see dense.h)
     int resume;          // fields_all holds the fields of the state the call starts from: no pass over J to rebuild them
     int persist;         // leave the fields of the final state in fields_all (the call's last sweep then updates every row)
@@ -506,7 +509,7 @@ __global__ __launch_bounds__(CO_THREADS) void k2_pipe(PipeParams P) {
     const TJ* __restrict__ J = (const TJ*)P.J;
     const TJ* __restrict__ JT = (const TJ*)P.JT;
     const int n = P.n, nsb = (n + SB - 1) / SB;
-    const double T = P.T, invT = 1.0 / P.T;
+    const double T = P.T;
     const unsigned n_stream = gridDim.x - NS;
     if (threadIdx.x == 0) {
         s_c1 = 0;
@@ -530,7 +533,8 @@ __global__ __launch_bounds__(CO_THREADS) void k2_pipe(PipeParams P) {
             const double* un = P.uniforms ? P.uniforms + (size_t)sw_of * n : nullptr;
             const double lgr = co_logit((uint32_t)r, un, tt, P.tag, P.k0, P.k1);
             const int sr = ld(P.state + r);
-            st(P.d0 + (r - q0), (int8_t)(co_decide(F, lgr, T, invT, (uint32_t)r, un, tt, P.tag, P.k0, P.k1) - sr));
+            const double Tw = P.temps ? P.temps[sw_of] : T;
+            st(P.d0 + (r - q0), (int8_t)(co_decide(F, lgr, Tw, 1.0 / Tw, (uint32_t)r, un, tt, P.tag, P.k0, P.k1) - sr));
         };
         auto signal_c1 = [&]() {  // this wave's stores are complete; the wave that completes the workgroup tells the solvers
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -677,6 +681,11 @@ __global__ __launch_bounds__(CO_THREADS) void k2_pipe(PipeParams P) {
     for (int sw = 0; sw < P.n_sweeps; ++sw) {
         const uint32_t t = P.sweep0 + (uint32_t)sw;
         const double* uni = P.uniforms ? P.uniforms + (size_t)sw * n : nullptr;
+        const double Tw = P.temps ? P.temps[sw] : T, invTw = 1.0 / Tw;  // (a schedule: one temperature per sweep)
+        // the state after this sweep is one of the recorded ones: the commits below write it there too
+        int8_t* rec = nullptr;
+        if (P.samples && sw + 1 > P.rec_from && (sw + 1 - P.rec_from) % P.rec_every == 0)
+            rec = P.samples + (size_t)((sw + 1 - P.rec_from) / P.rec_every - 1) * n;
         if (sw == 0 || ((sw + P.refresh_off) % CO_REFRESH) == 0) ++ev;
         for (int sb = 0; sb < nsb; ++sb) {
             const int p0 = sb * SB, pe = p0 + SB < n ? p0 + SB : n, cnt = pe - p0;
@@ -695,7 +704,7 @@ __global__ __launch_bounds__(CO_THREADS) void k2_pipe(PipeParams P) {
             const double fi = active ? ld(P.f + i) : 0.0;
             const int si = s_sb[il];
             double corr = 0.0;
-            bool flipped = active && co_decide(fi, lg, T, invT, (uint32_t)i, uni, t, P.tag, P.k0, P.k1) != si;
+            bool flipped = active && co_decide(fi, lg, Tw, invTw, (uint32_t)i, uni, t, P.tag, P.k0, P.k1) != si;
             int k = 0;
             while (true) {
                 // publish iteration k, then collect every group's iteration-k masks
@@ -771,7 +780,7 @@ __global__ __launch_bounds__(CO_THREADS) void k2_pipe(PipeParams P) {
                     if (!wg_wait_sharded(P.bar, PB_T(0), BAR_PAGE, tev, NS, (int)gridDim.x, &s_ok)) return;
                     if (owner) {
                         corr = active ? ld(P.corr + i) : 0.0;
-                        flipped = active && co_decide(fi + corr, lg, T, invT, (uint32_t)i, uni, t, P.tag, P.k0, P.k1) != si;
+                        flipped = active && co_decide(fi + corr, lg, Tw, invTw, (uint32_t)i, uni, t, P.tag, P.k0, P.k1) != si;
                     }
                     ++k;
                     PP_MARK(2);
@@ -820,7 +829,7 @@ __global__ __launch_bounds__(CO_THREADS) void k2_pipe(PipeParams P) {
 #pragma unroll
                     for (int u = 0; u < CO_THREADS / 64; ++u) tot += s_red[u][wv][lane];
                     corr += tot;
-                    flipped = active && co_decide(fi + corr, lg, T, invT, (uint32_t)i, uni, t, P.tag, P.k0, P.k1) != si;
+                    flipped = active && co_decide(fi + corr, lg, Tw, invTw, (uint32_t)i, uni, t, P.tag, P.k0, P.k1) != si;
                 }
                 ++k;
                 if (k > SB + 2) {  // cannot happen (the iteration is exact after SB rounds): report, leave
@@ -840,6 +849,7 @@ __global__ __launch_bounds__(CO_THREADS) void k2_pipe(PipeParams P) {
             if (owner && (lane & 3) == 0 && il < cnt) {  // cnt is a multiple of 4 (n is)
                 st(reinterpret_cast<unsigned*>(P.d1 + il), pd);
                 st(reinterpret_cast<unsigned*>(P.state + i), ps);
+                if (rec) *reinterpret_cast<unsigned*>(rec + i) = ps;
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -855,7 +865,8 @@ __global__ __launch_bounds__(CO_THREADS) void k2_pipe(PipeParams P) {
 
 template <typename TJ>
 static int pipe_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint32_t sweep0, uint32_t replica, bool have_uni,
-                      int* done, bool fields_were_valid) {
+                      int* done, bool fields_were_valid, const double* temps_dev = nullptr, int8_t* samples_dev = nullptr, int rec_from = 0,
+                      int rec_every = 1) {
     tsu_ctx* ctx = d->ctx;
     const int n = d->n;
     *done = 0;
@@ -948,6 +959,10 @@ static int pipe_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint3
         keep_fields = e ? atoi(e) : 1;
     }
     P.fields_all = d->co_fields;
+    P.temps = temps_dev;
+    P.samples = samples_dev;
+    P.rec_from = rec_from;
+    P.rec_every = rec_every > 0 ? rec_every : 1;
     P.resume = keep_fields && fields_were_valid && (d->since_refresh % CO_REFRESH) != 0 ? 1 : 0;
     P.refresh_off = P.resume ? d->since_refresh : 0;
     P.persist = keep_fields && d->pipe_streak >= 1 ? 1 : 0;
@@ -1115,6 +1130,24 @@ static int coop_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint3
     }
     *done = 1;
     return TSU_OK;
+}
+
+// a whole run (burn-in, then n_samples x n_sweeps sweeps with the state recorded after each group; or an annealing schedule: one
+// temperature per sweep) in ONE pipeline launch; *done = 0: the pipeline does not take it (the caller's loop of calls does)
+int tsu_dense_pipe_run(tsu_dense* d, double T, const double* temps_dev, int n_total, int rec_from, int rec_every, int8_t* samples_dev,
+                       uint64_t seed, uint32_t sweep0, uint32_t replica, bool have_uni, int* done) {
+    *done = 0;
+    const bool fields_were_valid = d->fields_valid != 0;
+    const int streak = d->pipe_streak;
+    d->fields_valid = 0;
+    d->pipe_streak = 0;
+    if (d->pp_failed || n_total <= 0) return TSU_OK;
+    d->pipe_streak = streak;
+    const int rc = d->dtype == TSU_DTYPE_F64
+                       ? pipe_sweep<double>(d, T, n_total, seed, sweep0, replica, have_uni, done, fields_were_valid, temps_dev, samples_dev, rec_from, rec_every)
+                       : pipe_sweep<float>(d, T, n_total, seed, sweep0, replica, have_uni, done, fields_were_valid, temps_dev, samples_dev, rec_from, rec_every);
+    if (!*done) d->pipe_streak = 0;
+    return rc;
 }
 
 int tsu_dense_coop_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint32_t sweep0, uint32_t replica, bool have_uni,
