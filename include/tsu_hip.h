@@ -206,6 +206,9 @@ int tsu_dense_sweep_replicas(tsu_dense* d, int n_replicas, const double* tempera
                              const uint64_t* seeds, const uint32_t* sweep0s, const uint32_t* replicas,
                              const double* replay_uniforms);
 int tsu_dense_energy(tsu_dense* d, double* energy); /* -1/2 s^T J s - b^T s of the resident state */
+/* the same for n_states given states (states_host: n_states x n bytes of 0/1; the resident state is not touched): the energies of
+ * the states an annealing schedule recorded (simulated_annealing, gibbs.py:384-391, evaluates compute_energy after every step) */
+int tsu_dense_energies(tsu_dense* d, const int8_t* states_host, int n_states, double* energies_host);
 
 /* ------------------------------------------------------------------ sparse coupling graph, colour-parallel (K5)
  * Replaces GibbsSampler.gibbs_sweep / sample_boltzmann / compute_energy (tsu/gibbs.py:79-236) for models whose

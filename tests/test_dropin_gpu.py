@@ -551,3 +551,39 @@ def test_parallel_tempering_mid_size_system_in_one_device_call_per_step():
     assert samples.shape == (40, n) and info["swap_attempts"] == 16
     e = np.array(info["energies"])
     assert e.shape == (3, 40) and e[0, 10:].mean() < e[1, 10:].mean() < e[2, 10:].mean()
+
+
+@pytest.mark.parametrize("n,order", [(600, "sequential"), (1100, "sequential"), (700, "random")])
+def test_simulated_annealing_of_a_large_system_follows_the_reference_loop(n, order):
+    """Above the size whose energies the host evaluates, simulated_annealing runs its schedule as device launches that record every
+    state and reads all their energies in one call.  With rng="numpy" the trajectory is the reference's (gibbs.py:340-393: start state,
+    then per step a permutation if the order is random and one uniform per visited site), and the state returned is the FIRST one
+    of the lowest energy."""
+    from tsu.gibbs import GibbsConfig, GibbsSampler
+    rng = np.random.default_rng(n)
+    J = rng.normal(size=(n, n)) / np.sqrt(n)
+    J = (J + J.T) / 2
+    b = rng.normal(size=n) * 0.1
+    steps = 25
+    np.random.seed(4242)
+    s = GibbsSampler(GibbsConfig(temperature=1.0, update_order=order), rng="numpy")
+    best, e = s.simulated_annealing(J, b, T_initial=3.0, T_final=0.05, n_steps=steps)
+    assert s.config.temperature == 3.0 * (0.05 / 3.0) ** ((steps - 1) / steps)
+    # the same loop, step by step, on the oracle
+    np.random.seed(4242)
+    state = np.random.randint(0, 2, size=n)
+    want_state, want_e = state.copy(), ora.ref_compute_energy(state, J, b)
+    for k in range(steps):
+        T = 3.0 * (0.05 / 3.0) ** (k / steps)
+        perm = np.random.permutation(n) if order == "random" else None
+        u = np.random.rand(1, n)
+        state = ora.c_dense_sweep_replay(state, J, b, T, u, order=None if perm is None else perm.reshape(1, n))
+        en = ora.ref_compute_energy(state, J, b)
+        if en < want_e - 1e-9 * n:  # (device energies differ from the host's by rounding: no near-ties in this instance)
+            want_e, want_state = en, state.copy()
+    np.testing.assert_array_equal(best, want_state)
+    assert abs(e - want_e) <= 1e-9 * n
+    # device RNG: the returned energy is the energy of the returned state, and annealing went downhill
+    s2 = GibbsSampler(GibbsConfig(temperature=1.0, update_order=order))
+    best2, e2 = s2.simulated_annealing(J, b, T_initial=3.0, T_final=0.05, n_steps=60)
+    assert abs(s2.compute_energy(best2, J, b) - e2) <= 1e-9 * n and e2 < want_e + 0.05 * abs(want_e)

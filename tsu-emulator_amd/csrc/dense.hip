@@ -1025,8 +1025,6 @@ static int dense_run(tsu_dense* d, double T, const double* temps, int n_burnin, 
     const size_t out_bytes = (size_t)n_samples * n;
     if (d->samples_cap < out_bytes) {
         if (d->samples) (void)hipFree(d->samples);
-    if (d->temps) (void)hipFree(d->temps);
-    if (d->rep_buf) (void)hipFree(d->rep_buf);
         d->samples = nullptr;
         d->samples_cap = 0;
         TSU_HIP_TRY(ctx, hipMalloc(&d->samples, out_bytes));
@@ -1039,7 +1037,6 @@ static int dense_run(tsu_dense* d, double T, const double* temps, int n_burnin, 
         if (temps && total > 0) {
             if (d->temps_cap < (size_t)total) {
                 if (d->temps) (void)hipFree(d->temps);
-    if (d->rep_buf) (void)hipFree(d->rep_buf);
                 d->temps = nullptr;
                 d->temps_cap = 0;
                 TSU_HIP_TRY(ctx, hipMalloc(&d->temps, (size_t)total * 8));
@@ -1231,6 +1228,46 @@ int tsu_dense_energy(tsu_dense* d, double* energy) {
     TSU_HIP_TRY(ctx, hipGetLastError());
     TSU_HIP_TRY(ctx, hipMemcpyAsync(energy, d->d_energy, 8, hipMemcpyDeviceToHost, ctx->stream));
     TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TSU_OK;
+}
+
+int tsu_dense_energies(tsu_dense* d, const int8_t* states_host, int n_states, double* energies_host) {
+    TSU_ENTER(d ? d->ctx : nullptr);
+    if (!d) return TSU_E_INVALID;
+    tsu_ctx* ctx = d->ctx;
+    TSU_REQUIRE(ctx, n_states >= 0 && (n_states == 0 || (states_host && energies_host)), "dense_energies: NULL / negative count");
+    if (n_states == 0) return TSU_OK;
+    const size_t n = (size_t)d->n;
+    for (size_t i = 0; i < n * (size_t)n_states; ++i)
+        TSU_REQUIRE(ctx, states_host[i] == 0 || states_host[i] == 1, "dense_energies: states must be 0/1");
+    // the states share the sample buffer (it is only ever a staging area of one call), the energies get a scratch array
+    if (d->samples_cap < n * (size_t)n_states) {
+        if (d->samples) (void)hipFree(d->samples);
+        d->samples = nullptr;
+        d->samples_cap = 0;
+        TSU_HIP_TRY(ctx, hipMalloc(&d->samples, n * (size_t)n_states));
+        d->samples_cap = n * (size_t)n_states;
+    }
+    double* d_e = nullptr;
+    TSU_HIP_TRY(ctx, hipMalloc(&d_e, (size_t)n_states * 8));
+    hipError_t e = hipMemcpyAsync(d->samples, states_host, n * (size_t)n_states, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_e, 0, (size_t)n_states * 8, ctx->stream);
+    const unsigned mv_grid = (unsigned)((n * 64 + 255) / 256);
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    for (int k = 0; k < n_states && e == hipSuccess; ++k) {  // one pass over J per state, all on the stream, one wait at the end
+        const int8_t* s = d->samples + (size_t)k * n;
+        if (d->dtype == TSU_DTYPE_F64)
+            k2_matvec<double><<<mv_grid, 256, 0, ctx->stream>>>((const double*)d->J, s, d->bias, d->field, d->n);
+        else
+            k2_matvec<float><<<mv_grid, 256, 0, ctx->stream>>>((const float*)d->J, s, d->bias, d->field, d->n);
+        k2_energy<<<blocks, 256, 0, ctx->stream>>>(d->field, s, d->bias, d_e + k, d->n);
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(energies_host, d_e, (size_t)n_states * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_e);
+    if (e != hipSuccess) return tsu_fail(ctx, TSU_E_HIP, "dense_energies: %s", hipGetErrorString(e));
     return TSU_OK;
 }
 

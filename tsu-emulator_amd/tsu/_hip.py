@@ -89,6 +89,7 @@ SIGNATURES = {
     "tsu_dense_anneal": (C.c_int, [_vp, _f64p, C.c_int, _i64p, C.c_uint64, C.c_uint32, C.c_uint32, _f64p, _i8p]),
     "tsu_dense_sweep_replicas": (C.c_int, [_vp, C.c_int, _f64p, C.c_int, _i8p, _u64p, _u32p, _u32p, _f64p]),
     "tsu_dense_energy": (C.c_int, [_vp, _f64p]),
+    "tsu_dense_energies": (C.c_int, [_vp, _i8p, C.c_int, _f64p]),
     "tsu_sparse_create": (C.c_int, [_vp, C.c_int, _i64p, _i32p, _f64p, _f64p, C.c_int, _i32p, _i32p, C.POINTER(_vp)]),
     "tsu_sparse_destroy": (C.c_int, [_vp]),
     "tsu_sparse_set_state": (C.c_int, [_vp, _i8p]),
@@ -431,6 +432,14 @@ class DenseSystem:
         e = C.c_double(0)
         self.ctx.check(self.lib.tsu_dense_energy(self.h, C.byref(e)))
         return e.value
+
+    def energies(self, states):
+        """Energies of the given states ((k, n) of 0/1), evaluated on the device in one call; the resident state stays as it is."""
+        st = np.ascontiguousarray(states, dtype=np.int8).reshape(-1, self.n)
+        out = np.empty(st.shape[0], dtype=np.float64)
+        if st.shape[0]:
+            self.ctx.check(self.lib.tsu_dense_energies(self.h, _ptr(st, _i8p), int(st.shape[0]), _ptr(out, _f64p)))
+        return out
 
 
 def comm_unique_id() -> bytes:

@@ -481,23 +481,7 @@ class GibbsSampler:
         else:  # linear
             temps = [T_initial + (T_final - T_initial) * step / n_steps for step in range(n_steps)]
         if n_bits > self._ANNEAL_HOST_ENERGY_MAX:
-            # large systems: energies by the device reduction, one step at a time; J is hashed/uploaded once for the
-            # whole schedule (no caller code runs inside this loop, so the arrays cannot change under it)
-            held_before = self._held
-            self.bind(coupling, bias)
-            try:
-                best_state = state.copy()
-                best_energy = self.compute_energy(state, coupling, bias)
-                for T in temps:
-                    self.config.temperature = T
-                    state = self.gibbs_sweep(state, coupling, bias, n_sweeps=1)
-                    energy = self.compute_energy(state, coupling, bias)
-                    if energy < best_energy:
-                        best_energy = energy
-                        best_state = state.copy()
-            finally:
-                self._held = held_before
-            return best_state, best_energy
+            return self._anneal_dense_large(coupling, bias, state, temps)
         # the whole schedule in one device call (one sweep per temperature, every state recorded); the energies and the
         # running minimum are evaluated here with the reference's own expression (gibbs.py:233-236), so that ties
         # between equal-energy states break as they do there
@@ -532,6 +516,46 @@ class GibbsSampler:
                 if energy < best_energy:
                     best_energy = energy
                     best_state = cand
+        return best_state, best_energy
+
+    def _anneal_dense_large(self, coupling, bias, state, temps):
+        """simulated_annealing above the size whose energies are cheap on the host: the schedule runs in device calls of up to
+        2**26 / n steps (each ONE launch: a temperature per sweep, every state recorded in the kernel), the energies of the recorded
+        states come from one ``tsu_dense_energies`` call per chunk, and the running minimum keeps the first state of the lowest
+        energy, as the reference's ``energy < best_energy`` does (gibbs.py:384-391).  J is hashed / uploaded once."""
+        n_bits = coupling.shape[0]
+        for T in temps:
+            if T <= 0:
+                raise ValueError("Temperature must be positive")
+        sys = self._system(coupling, bias)
+        sys.set_state(self._as_bits(state, n_bits))
+        best_state, best_energy = state.copy(), float(sys.energy())
+        random_order = self.config.update_order == "random"
+        chunk = max(1, min(len(temps), (1 << 26) // n_bits))
+        for c0 in range(0, len(temps), chunk):
+            tt = temps[c0:c0 + chunk]
+            m = len(tt)
+            order = np.array([np.random.permutation(n_bits) for _ in range(m)]).reshape(m, n_bits) if random_order and self.rng != "numpy" else None
+            if self.rng == "numpy":
+                if random_order:  # the reference draws a permutation, then the sweep's uniforms, step by step
+                    order = np.empty((m, n_bits), dtype=np.int64)
+                    uni = np.empty((m, n_bits), dtype=np.float64)
+                    for s_ in range(m):
+                        order[s_] = np.random.permutation(n_bits)
+                        uni[s_] = np.random.rand(n_bits)
+                else:
+                    uni = np.random.rand(m, n_bits)
+                states = sys.anneal(tt, order=order, replay_uniforms=uni)
+            else:
+                states = sys.anneal(tt, seed=self._philox_seed(), sweep0=self._sweep_counter, order=order)
+                self._sweep_counter += m
+            energies = sys.energies(states)
+            k = int(np.argmin(energies))  # the first of equal minima, like the strict comparison step by step
+            if energies[k] < best_energy:
+                best_energy = float(energies[k])
+                best_state = states[k].astype(state.dtype)
+        if temps:
+            self.config.temperature = temps[-1]
         return best_state, best_energy
 
     def _anneal_sparse(self, coupling, bias, T_initial, T_final, n_steps, cooling_schedule):
