@@ -583,6 +583,9 @@ def test_simulated_annealing_of_a_large_system_follows_the_reference_loop(n, ord
             want_e, want_state = en, state.copy()
     np.testing.assert_array_equal(best, want_state)
     assert abs(e - want_e) <= 1e-9 * n
+    # a second, longer schedule on the same sampler (same device system: its sample / temperature buffers grow)
+    best_b, e_b = s.simulated_annealing(J, b, T_initial=3.0, T_final=0.05, n_steps=70)
+    assert abs(s.compute_energy(best_b, J, b) - e_b) <= 1e-9 * n
     # device RNG: the returned energy is the energy of the returned state, and annealing went downhill
     s2 = GibbsSampler(GibbsConfig(temperature=1.0, update_order=order))
     best2, e2 = s2.simulated_annealing(J, b, T_initial=3.0, T_final=0.05, n_steps=60)
