@@ -590,3 +590,31 @@ def test_simulated_annealing_of_a_large_system_follows_the_reference_loop(n, ord
     s2 = GibbsSampler(GibbsConfig(temperature=1.0, update_order=order))
     best2, e2 = s2.simulated_annealing(J, b, T_initial=3.0, T_final=0.05, n_steps=60)
     assert abs(s2.compute_energy(best2, J, b) - e2) <= 1e-9 * n and e2 < want_e + 0.05 * abs(want_e)
+
+
+def test_a_state_handed_back_unchanged_is_not_uploaded_again_and_a_changed_one_is():
+    """state = sampler.gibbs_sweep(state, J) in a loop with compute_energy in between: the wrapper keeps a host mirror of the resident
+    state, so the state it just returned is not uploaded again (and the library keeps its fields for it); any other state is."""
+    from tsu.gibbs import GibbsConfig, GibbsSampler
+    n = 600
+    rng = np.random.default_rng(9)
+    J = rng.normal(size=(n, n)) / np.sqrt(n)
+    J = (J + J.T) / 2
+    b = rng.normal(size=n) * 0.2
+    np.random.seed(77)
+    s = GibbsSampler(GibbsConfig(temperature=0.8), rng="numpy")
+    s.bind(J, b)
+    state = np.random.randint(0, 2, size=n)
+    want = state.copy()
+    for k in range(6):
+        if k == 3:  # not the state that was handed back: it must reach the device
+            state = state.copy()
+            state[17] ^= 1
+            want = state.copy()
+        u = np.random.get_state()
+        state = s.gibbs_sweep(state, J, b, n_sweeps=2)
+        np.random.set_state(u)
+        want = ora.c_dense_sweep_replay(want, J, b, 0.8, np.random.rand(2, n))
+        np.testing.assert_array_equal(state, want, err_msg=f"step {k}")
+        assert abs(s.compute_energy(state, J, b) - ora.ref_compute_energy(want, J, b)) <= 1e-9 * n
+    s.unbind()

@@ -366,6 +366,10 @@ class DenseSystem:
         self.ctx.check(self.lib.tsu_dense_create(self.ctx.h, self.n, Jc.ctypes.data_as(_vp), int(dtype),
                                                  None if b is None else _ptr(b, _f64p), C.byref(h)))
         self.h = h
+        # host mirror of the resident state, valid right after set_state / get_state: a caller that hands back the state it was
+        # just given (the functional gibbs_sweep(state, ...) -> state idiom, compute_energy of that state) does not upload it again --
+        # and the library keeps the fields J s + b it holds for exactly that state (tsu_dense_set_state would drop them)
+        self._mirror = None
 
     def close(self):
         if getattr(self, "h", None):
@@ -378,17 +382,22 @@ class DenseSystem:
 
     def set_state(self, bits):
         b = np.ascontiguousarray(bits, dtype=np.int8).reshape(self.n)
+        if self._mirror is not None and np.array_equal(b, self._mirror):
+            return  # the device already holds exactly this state
         self.ctx.check(self.lib.tsu_dense_set_state(self.h, _ptr(b, _i8p)))
+        self._mirror = b.copy()
 
     def get_state(self):
         out = np.empty(self.n, dtype=np.int8)
         self.ctx.check(self.lib.tsu_dense_get_state(self.h, _ptr(out, _i8p)))
+        self._mirror = out.copy()
         return out
 
     def sweep(self, T, n_sweeps, seed=0, sweep0=0, replica=0, order=None, replay_uniforms=None):
         o = None if order is None else np.ascontiguousarray(order, dtype=np.int64).reshape(n_sweeps, self.n)
         u = None if replay_uniforms is None else np.ascontiguousarray(replay_uniforms, dtype=np.float64).reshape(
             n_sweeps, self.n)
+        self._mirror = None
         self.ctx.check(self.lib.tsu_dense_sweep(self.h, float(T), int(n_sweeps), None if o is None else _ptr(o, _i64p),
                                                 int(seed), int(sweep0), int(replica),
                                                 None if u is None else _ptr(u, _f64p)))
@@ -399,6 +408,7 @@ class DenseSystem:
         o = None if order is None else np.ascontiguousarray(order, dtype=np.int64).reshape(total, self.n)
         u = None if replay_uniforms is None else np.ascontiguousarray(replay_uniforms, dtype=np.float64).reshape(total, self.n)
         out = np.empty((int(n_samples), self.n), dtype=np.int8)
+        self._mirror = None
         self.ctx.check(self.lib.tsu_dense_sample(self.h, float(T), int(n_burnin), int(n_sweeps), int(n_samples),
                                                  None if o is None else _ptr(o, _i64p), int(seed), int(sweep0), int(replica),
                                                  None if u is None else _ptr(u, _f64p), _ptr(out, _i8p)))
@@ -411,6 +421,7 @@ class DenseSystem:
         o = None if order is None else np.ascontiguousarray(order, dtype=np.int64).reshape(steps, self.n)
         u = None if replay_uniforms is None else np.ascontiguousarray(replay_uniforms, dtype=np.float64).reshape(steps, self.n)
         out = np.empty((steps, self.n), dtype=np.int8)
+        self._mirror = None
         self.ctx.check(self.lib.tsu_dense_anneal(self.h, _ptr(t, _f64p), steps, None if o is None else _ptr(o, _i64p), int(seed),
                                                  int(sweep0), int(replica), None if u is None else _ptr(u, _f64p), _ptr(out, _i8p)))
         return out
@@ -424,6 +435,7 @@ class DenseSystem:
         s0 = np.ascontiguousarray(sweep0s, dtype=np.uint32).reshape(R)
         rp = np.zeros(R, dtype=np.uint32) if replicas is None else np.ascontiguousarray(replicas, dtype=np.uint32).reshape(R)
         u = None if replay_uniforms is None else np.ascontiguousarray(replay_uniforms, dtype=np.float64).reshape(R, int(n_sweeps), self.n)
+        self._mirror = None  # (systems beyond the one-workgroup kernels are swept replica by replica through the resident state)
         self.ctx.check(self.lib.tsu_dense_sweep_replicas(self.h, R, _ptr(t, _f64p), int(n_sweeps), _ptr(st, _i8p), _ptr(sd, _u64p),
                                                          _ptr(s0, _u32p), _ptr(rp, _u32p), None if u is None else _ptr(u, _f64p)))
         return st
