@@ -268,3 +268,41 @@ def test_bench_refuses_a_world_that_is_not_the_one_requested():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()
+
+
+def test_parallel_tempering_does_not_leave_a_stale_bind_behind(monkeypatch):
+    """bind(J1); parallel_tempering(J2) replaces the device copy by J2's: afterwards a call with J1 must not be served from it
+    (ADVICE round 2).  Host logic only: the device system is a stand-in that remembers which matrix it was built from."""
+    import numpy as np
+    from tsu import gibbs, _hip
+
+    class FakeSystem:
+        def __init__(self, J, bias, dtype):
+            self.J, self.n = np.array(J), np.asarray(J).shape[0]
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(_hip, "DenseSystem", FakeSystem)
+    s = gibbs.GibbsSampler(gibbs.GibbsConfig(n_burnin=0, n_sweeps=1), seed=1)
+    monkeypatch.setattr(s, "_parallel_tempering_run", lambda *a, **k: (np.zeros((0, 4)), {}))
+    J1, J2 = np.eye(4), 2.0 * np.eye(4)
+    s.bind(J1)
+    assert s._system(J1, None).J[0, 0] == 1.0
+    s.parallel_tempering(J2, [1.0, 2.0], n_samples=0)
+    assert s._system(J1, None).J[0, 0] == 1.0, "J1 served from J2's device copy"
+    # a bind of the very arrays the tempering call uses survives it
+    s.bind(J2)
+    s.parallel_tempering(J2, [1.0, 2.0], n_samples=0)
+    assert s._held is not None and s._held[0] is J2
+    assert s._system(J2, None).J[0, 0] == 2.0
+
+
+def test_sample_chains_checks_the_sweep_counter_like_the_c_abi(monkeypatch):
+    import numpy as np
+    import pytest
+    from tsu import gibbs
+    s = gibbs.GibbsSampler(gibbs.GibbsConfig(n_burnin=1, n_sweeps=1), seed=1)
+    s._sweep_counter = 2 ** 32 - 5
+    with pytest.raises(ValueError, match="sweep counter overflow"):
+        s.sample_chains(np.eye(4), 4, 1)

@@ -338,6 +338,8 @@ class GibbsSampler:
         if T <= 0:
             raise ValueError("Temperature must be positive")
         per_chain = burnin + n_samples_per_chain * n_sweeps
+        if self._sweep_counter + n_chains * per_chain > 2 ** 32:  # the message of the C ABI's check on the one-by-one path
+            raise ValueError("dense_sample: sweep counter overflow")
         sys = self._system(coupling, bias)
         seed = self._philox_seed()
         out = np.zeros((n_chains, n_samples_per_chain, n_bits), dtype=int)
@@ -404,7 +406,12 @@ class GibbsSampler:
             return self._parallel_tempering_run(samplers, states, coupling, bias, temperatures, n_samples, swap_interval,
                                                 energy_of)
         finally:
-            self._held = held_before
+            # bind() above replaced the device copy by this call's J: an earlier bind is only still served by it when it named
+            # these very arrays; any other earlier bind is dropped (the next call takes the content-hash path and uploads again)
+            if held_before is not None and held_before[0] is coupling and held_before[1] is bias:
+                self._held = held_before
+            else:
+                self._held = None
             for rep in samplers:
                 rep.invalidate()
 
