@@ -306,3 +306,24 @@ def test_sample_chains_checks_the_sweep_counter_like_the_c_abi(monkeypatch):
     s._sweep_counter = 2 ** 32 - 5
     with pytest.raises(ValueError, match="sweep counter overflow"):
         s.sample_chains(np.eye(4), 4, 1)
+
+
+def test_large_dim_energy_callables_are_probed_in_bounded_time_or_refused():
+    """A callable energy with d > 4096: a uniform separable quadratic is recognised with ~140 evaluations whatever d is; anything
+    else is refused with the descriptor to use instead of silently starting the O(d^2) finite-difference loop on the host."""
+    import time
+    import numpy as np
+    import pytest
+    from tsu import core
+    t0 = time.perf_counter()
+    q = core._recognise_quadratic(lambda x: (x ** 2).sum(), np.zeros(2 ** 18))
+    assert q is not None and float(q.k) == 2.0 and float(q.mu) == 0.0 and q.c == 0.0
+    q = core._recognise_quadratic(lambda x: 1.5 * ((x - 0.25) ** 2).sum() + 7.0, np.ones(2 ** 16))
+    assert q is not None and float(q.k) == 3.0 and float(q.mu) == 0.25 and abs(q.c - 7.0) < 1e-6
+    assert core._recognise_quadratic(lambda x: (x ** 4).sum(), np.zeros(2 ** 16)) is None
+    assert core._recognise_quadratic(lambda x: (x ** 2).sum() + x[5] ** 2, np.zeros(2 ** 16)) is None  # one deviating coordinate
+    assert core._recognise_quadratic(lambda x: (x ** 2).sum() + x[0] * x[1], np.zeros(2 ** 16)) is None  # coupled
+    tsu = core.ThermalSamplingUnit(core.TSUConfig(n_burnin=10, n_steps=10), seed=1)
+    with pytest.raises(core.SamplingError, match="QuadraticEnergy"):
+        tsu.sample_boltzmann(lambda x: (x ** 4).sum(), n_samples=2, dim=2 ** 16)
+    assert time.perf_counter() - t0 < 5.0

@@ -11,7 +11,7 @@ pids=()
 for src in "$HERE"/*.hip; do
     obj="$HERE/_obj/$(basename "${src%.hip}").o"
     objs+=("$obj")
-    if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/tsu_common.h" -nt "$obj" ] || [ "$HERE/ising2d.h" -nt "$obj" ] || [ "$HERE/dense.h" -nt "$obj" ] || [ "$HERE/../../include/tsu_hip.h" -nt "$obj" ]; then
+    if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/tsu_common.h" -nt "$obj" ] || [ "$HERE/ising2d.h" -nt "$obj" ] || [ "$HERE/dense.h" -nt "$obj" ] || [ "$HERE/dense_dev.h" -nt "$obj" ] || [ "$HERE/../../include/tsu_hip.h" -nt "$obj" ]; then
         $HIPCC $FLAGS ${TSU_EXTRA_FLAGS:-} -c "$src" -o "$obj" &
         pids+=($!)
     fi

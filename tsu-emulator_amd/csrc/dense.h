@@ -48,6 +48,16 @@ struct tsu_dense {
     int fields_valid;   // co_fields belongs to d->state (cleared by everything else that writes the state)
     int since_refresh;  // sweeps since the fields were last computed from scratch (CO_REFRESH bounds the drift across calls too)
     int pipe_streak;    // consecutive pipeline calls on this state: the second one starts to keep the fields
+    // owner-computes kernel (dense_own.hip): value-mask granules of the running generation and of the superblocks' final values
+    unsigned long long* own_gran;
+    size_t own_cap;     // 8-byte words allocated in own_gran
+    int own_failed;     // k2_own ran and gave up half way: the caller restores the state, later calls skip it
+};
+
+// per-replica parameters of a k2_own launch
+struct OwnRep {
+    double T;
+    uint32_t sweep0, tag, k0, k1;
 };
 
 
@@ -87,6 +97,11 @@ static __device__ __forceinline__ int dense_decide(double F, double lg, double T
 // cooperative single-launch sweep (dense_coop.hip): TSU_OK with *done = 1 when the call was carried out, *done = 0
 // when the path is unavailable or a superblock did not converge (state untouched or restored by the caller)
 int tsu_dense_pipe_run(tsu_dense* d, double T, const double* temps_dev, int n_total, int rec_from, int rec_every, int8_t* samples_dev,
-                       uint64_t seed, uint32_t sweep0, uint32_t replica, bool have_uni, int* done);
+                       uint64_t seed, uint32_t sweep0, uint32_t replica, bool have_uni, int* done, const int64_t* order_dev = nullptr);
+// owner-computes kernel (dense_own.hip): n_sweeps sweeps of R states ([R][n] at states_dev; R == 1: d->state) in one launch, natural
+// order or the caller's (order_dev: [n_sweeps][n]); *done as above
+int tsu_dense_own_run(tsu_dense* d, int R, const OwnRep* reps, int8_t* states_dev, int n_sweeps, const double* uniforms_dev,
+                      const int64_t* order_dev, const double* temps_dev, int8_t* samples_dev, int rec_from, int rec_every, bool fields_were_valid,
+                      bool allow_persist, int* done);
 int tsu_dense_coop_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint32_t sweep0, uint32_t replica,
-                         bool have_uni, int* done);
+                         bool have_uni, int* done, const int64_t* order_dev = nullptr);

@@ -878,6 +878,7 @@ int tsu_dense_destroy(tsu_dense* d) {
     if (d->co_bar) (void)hipFree(d->co_bar);
     if (d->pp_masks) (void)hipFree(d->pp_masks);
     if (d->co_fields) (void)hipFree(d->co_fields);
+    if (d->own_gran) (void)hipFree(d->own_gran);
     delete d;
     return TSU_OK;
 }
@@ -966,6 +967,15 @@ int tsu_dense_sweep(tsu_dense* d, double T, int n_sweeps, const int64_t* order, 
             fprintf(stderr, "[tsu] k2_wg n=%d: %d sweeps, slowest fixed point %u iterations\n", d->n, n_sweeps, w);
         }
         return TSU_OK;
+    }
+    if (order && d->n >= 2 * DB) {
+        // a caller's visiting order (update_order="random"): the owner-computes kernel follows it in one launch (dense_own.hip);
+        // it declines small systems and reports a failed run with done = 0 -- then the block-by-block path below takes the call
+        TSU_HIP_TRY(ctx, hipMemcpyAsync(d->backup, d->state, (size_t)d->n, hipMemcpyDeviceToDevice, ctx->stream));
+        int done = 0;
+        const int rc = tsu_dense_coop_sweep(d, T, n_sweeps, seed, sweep0, replica, replay_uniforms != nullptr, &done, d->order);
+        if (rc != TSU_OK) return rc;
+        if (done) return TSU_OK;
     }
     static int use_sb = -1, use_coop = -1;
     if (use_sb < 0) {
@@ -1072,7 +1082,8 @@ static int dense_run(tsu_dense* d, double T, const double* temps, int n_burnin, 
             one_launch = e ? atoi(e) : 1;
         }
         const size_t ucnt = (size_t)total * n;
-        if (one_launch && !order && total > 0 && !d->co_disabled && n >= 2 * DB && (!replay_uniforms || ucnt * 8 <= ((size_t)1 << 29))) {
+        if (one_launch && total > 0 && (order || !d->co_disabled) && n >= 2 * DB && (!replay_uniforms || ucnt * 8 <= ((size_t)1 << 29)) &&
+            (!order || ucnt * 8 <= ((size_t)1 << 29))) {
             const double* temps_dev = nullptr;
             if (temps) {  // (a schedule: n_burnin == 0, n_sweeps == 1, one temperature per recorded state)
                 if (d->temps_cap < (size_t)total) {
@@ -1095,10 +1106,29 @@ static int dense_run(tsu_dense* d, double T, const double* temps, int n_burnin, 
                 }
                 TSU_HIP_TRY(ctx, hipMemcpyAsync(d->uniforms, replay_uniforms, ucnt * 8, hipMemcpyHostToDevice, ctx->stream));
             }
+            if (order) {  // (validated as permutations by tsu_dense_sweep's check, repeated here for the one-launch path)
+                std::vector<char> seen((size_t)n);
+                for (long long sw = 0; sw < total; ++sw) {
+                    std::fill(seen.begin(), seen.end(), 0);
+                    for (int i = 0; i < n; ++i) {
+                        const long long v = order[(size_t)sw * n + i];
+                        TSU_REQUIRE(ctx, v >= 0 && v < n && !seen[(size_t)v], "dense_sweep: order row %d is not a permutation of 0..%d", (int)sw, n - 1);
+                        seen[(size_t)v] = 1;
+                    }
+                }
+                if (d->order_cap < ucnt) {
+                    if (d->order) (void)hipFree(d->order);
+                    d->order = nullptr;
+                    d->order_cap = 0;
+                    TSU_HIP_TRY(ctx, hipMalloc(&d->order, ucnt * 8));
+                    d->order_cap = ucnt;
+                }
+                TSU_HIP_TRY(ctx, hipMemcpyAsync(d->order, order, ucnt * 8, hipMemcpyHostToDevice, ctx->stream));
+            }
             TSU_HIP_TRY(ctx, hipMemcpyAsync(d->backup, d->state, (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
             int done = 0;
             const int rc1 = tsu_dense_pipe_run(d, T, temps_dev, (int)total, n_burnin, n_sweeps, d->samples, seed, sweep0, replica, replay_uniforms != nullptr,
-                                               &done);
+                                               &done, order ? d->order : nullptr);
             if (rc1 != TSU_OK) return rc1;
             if (done) {
                 if (out_bytes) TSU_HIP_TRY(ctx, hipMemcpyAsync(samples_host, d->samples, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -1160,8 +1190,57 @@ int tsu_dense_sweep_replicas(tsu_dense* d, int n_replicas, const double* tempera
     if (n_sweeps == 0) return TSU_OK;
     const int wave_m = k2w_slots(d);
     const bool wg = !wave_m && k2wg_takes(d);
-    if (!wave_m && !wg) {  // larger systems: one replica after the other through the sweep paths
-        for (int r = 0; r < n_replicas; ++r) {
+    if (!wave_m && !wg) {
+        // larger systems: up to eight replicas advance together in one launch of the owner-computes kernel (dense_own.hip: every row
+        // of J^T is loaded once for all of them), groups of eight one after the other; if the kernel declines, one replica after the
+        // other through the sweep paths
+        bool all_done = true;
+        int r_done = 0;  // replicas whose final states are already in states_host
+        for (int r0 = 0; r0 < n_replicas && all_done; r0 += 8) {
+            const int m = n_replicas - r0 < 8 ? n_replicas - r0 : 8;
+            if (m == 1) {
+                all_done = false;
+                break;
+            }
+            const int mp = m <= 2 ? 2 : m <= 4 ? 4 : 8;  // (padding replicas repeat the group's first one; their results are dropped)
+            const size_t sb_ = (size_t)mp * n, ub_ = replay_uniforms ? (size_t)mp * n_sweeps * n * 8 : 0;
+            const size_t need_ = ((sb_ + 7) / 8) * 8 + ub_;
+            if (d->rep_cap < need_) {
+                if (d->rep_buf) (void)hipFree(d->rep_buf);
+                d->rep_buf = nullptr;
+                d->rep_cap = 0;
+                TSU_HIP_TRY(ctx, hipMalloc(&d->rep_buf, need_));
+                d->rep_cap = need_;
+            }
+            int8_t* ds = (int8_t*)d->rep_buf;
+            double* du = ub_ ? (double*)((char*)d->rep_buf + ((sb_ + 7) / 8) * 8) : nullptr;
+            OwnRep reps[8];
+            for (int q = 0; q < mp; ++q) {
+                const int r = r0 + (q < m ? q : 0);
+                reps[q].T = temperatures[r];
+                reps[q].sweep0 = sweep0s[r];
+                reps[q].tag = TSU_TAG_DENSE | (replicas[r] << 8);
+                reps[q].k0 = (uint32_t)seeds[r];
+                reps[q].k1 = (uint32_t)(seeds[r] >> 32);
+                TSU_HIP_TRY(ctx, hipMemcpyAsync(ds + (size_t)q * n, states_host + (size_t)r * n, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+                if (du)
+                    TSU_HIP_TRY(ctx, hipMemcpyAsync(du + (size_t)q * n_sweeps * n, replay_uniforms + (size_t)r * n_sweeps * n, (size_t)n_sweeps * n * 8,
+                                                    hipMemcpyHostToDevice, ctx->stream));
+            }
+            int done = 0;
+            const int rc = tsu_dense_own_run(d, mp, reps, ds, n_sweeps, du, nullptr, nullptr, nullptr, 0, 1, false, false, &done);
+            if (rc != TSU_OK) return rc;
+            if (!done) {
+                d->own_failed = 0;  // (the replicas' states live in a scratch buffer: nothing of the system was touched)
+                all_done = false;
+                break;
+            }
+            TSU_HIP_TRY(ctx, hipMemcpyAsync(states_host + (size_t)r0 * n, ds, (size_t)m * n, hipMemcpyDeviceToHost, ctx->stream));
+            TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            r_done = r0 + m;
+        }
+        if (all_done) return TSU_OK;
+        for (int r = r_done; r < n_replicas; ++r) {  // (the groups that ran are finished: only the others)
             int rc = tsu_dense_set_state(d, states_host + (size_t)r * n);
             if (rc == TSU_OK)
                 rc = tsu_dense_sweep(d, temperatures[r], n_sweeps, nullptr, seeds[r], sweep0s[r], replicas[r],

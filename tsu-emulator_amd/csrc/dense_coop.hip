@@ -19,13 +19,11 @@
 //   I*  while the list is not empty: c_i += sum_{(j, D) in list, j < i} J_ij D; re-decide; changed -> next list   B
 //   C   s'_i = s_i + d1_i; later rows r: f_r += J[r, p0:p0+cnt].d1, and d0_r = decide(f_r) - s_r for the next
 //       superblock's rows                                                                                         B
-#include "dense.h"
+#include "dense_dev.h"
 
 #define CO_THREADS 1024
 #define CO_MAX_N 65536         // bytes of LDS for the staged state vector (phase A)
-#define CO_REFRESH 64          // sweeps between two full recomputations of the fields (bounds floating-point drift)
 #define CO_SLOTS 64            // iterations recorded per superblock; more than that = not converged (never seen)
-#define CO_TIMEOUT 400000000ll // wall_clock64 ticks (100 MHz): 4 s
 
 struct CoopParams {
     const void* J;
@@ -59,36 +57,10 @@ struct CoopParams {
 //     the barrier's own counters rely on).  J, the bias and replayed uniforms are read-only and cached normally.
 //     Vectors that every wave needs (the state in phase A, the flips in T and C) are staged once per workgroup into
 //     LDS.  A wave's stores are complete (s_waitcnt vmcnt(0)) before its workgroup arrives.
-#define BAR_PAGE 1024                 // unsigned per 4 KiB page
-#define BAR_GROUPS 16
-#define BAR_CNT(g) ((g) * BAR_PAGE)
-#define BAR_GEN(g) ((BAR_GROUPS + (g)) * BAR_PAGE)
-#define BAR_ROOT (2 * BAR_GROUPS * BAR_PAGE)
-#define BAR_GSIZE(g) ((2 * BAR_GROUPS + 1) * BAR_PAGE + (g))
-#define BAR_SETUP ((2 * BAR_GROUPS + 2) * BAR_PAGE)
-#define BAR_ERR ((2 * BAR_GROUPS + 3) * BAR_PAGE)      // [0] error flag, [1] slowest fixed point, [2] not-converged flag
-#define BAR_WORDS ((2 * BAR_GROUPS + 4) * BAR_PAGE)
-
 struct GridBar {
     unsigned* bar;
     unsigned g, gsize, ng, epoch;
 };
-
-static __device__ __forceinline__ bool bar_wait(unsigned* bar, const unsigned* word, unsigned target) {
-    // one agent-scope load per poll (the load's own latency is the back-off); the error flag and the clock are looked at
-    // every 64th poll only -- checking them every time doubled the time a barrier takes to release
-    const long long t0 = wall_clock64();
-    for (unsigned spins = 0;; ++spins) {
-        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
-        if ((spins & 63u) == 63u) {
-            if (__hip_atomic_load(&bar[BAR_ERR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
-            if (wall_clock64() - t0 > CO_TIMEOUT) {
-                __hip_atomic_store(&bar[BAR_ERR], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
-        }
-    }
-}
 
 // once per kernel: which XCD am I on, how many workgroups share it, how many XCDs take part (one flat barrier)
 static __device__ __forceinline__ bool grid_bar_init(GridBar& B, unsigned* bar) {
@@ -151,39 +123,6 @@ struct JVec<double> {
     typedef double2 raw;
     static __device__ __forceinline__ double get(const raw& q, int e) { return e == 0 ? q.x : q.y; }
 };
-
-// dense_decide (dense.h) with the rare close call out of line: the float64 exp and the Philox block it needs would
-// otherwise be inlined at every decision site and push the kernel past its 128 VGPRs
-static __device__ __noinline__ int co_decide_exact(double F, double T, uint32_t site, const double* __restrict__ uniforms,
-                                                   uint32_t sweep, uint32_t tag, uint32_t k0, uint32_t k1) {
-    const double u = uniforms ? uniforms[site] : dense_uniform(site, sweep, tag, k0, k1);
-    return (u < sigmoid_clamped(F / T)) ? 1 : 0;
-}
-static __device__ __forceinline__ int co_decide(double F, double lg, double T, double invT, uint32_t site,
-                                                const double* __restrict__ uniforms, uint32_t sweep, uint32_t tag, uint32_t k0,
-                                                uint32_t k1) {
-    const double xa = F * invT;
-    if (fabs(fabs(xa) - 20.0) < 1e-9 || fabs(xa - lg) <= 1e-9 * (1.0 + fabs(lg)))
-        return co_decide_exact(F, T, site, uniforms, sweep, tag, k0, k1);
-    if (xa > 20.0) return 1;
-    if (xa < -20.0) return 0;
-    return xa > lg ? 1 : 0;
-}
-static __device__ __noinline__ double co_logit(uint32_t site, const double* __restrict__ uniforms, uint32_t sweep, uint32_t tag,
-                                               uint32_t k0, uint32_t k1) {
-    const double u = uniforms ? uniforms[site] : dense_uniform(site, sweep, tag, k0, k1);
-    return log(u) - log1p(-u);
-}
-
-// agent-scope accesses for data shared between workgroups inside the kernel (see the barrier's note)
-template <typename V>
-static __device__ __forceinline__ V ld(const V* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <typename V>
-static __device__ __forceinline__ void st(V* p, V v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // the workgroup copies w[c0, c1) (c0 a multiple of 4) into LDS; the caller synchronises
 static __device__ __forceinline__ void stage_weights(const int8_t* w, int c0, int c1, int8_t* wl) {
@@ -1132,16 +1071,41 @@ static int coop_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint3
     return TSU_OK;
 }
 
+// the owner-computes kernel (dense_own.hip) for one state: same contract as pipe_sweep
+static int own_try(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint32_t sweep0, uint32_t replica, bool have_uni, const int64_t* order_dev,
+                   const double* temps_dev, int8_t* samples_dev, int rec_from, int rec_every, bool fields_were_valid, int* done) {
+    OwnRep rep;
+    rep.T = T;
+    rep.sweep0 = sweep0;
+    rep.tag = TSU_TAG_DENSE | (replica << 8);
+    rep.k0 = (uint32_t)seed;
+    rep.k1 = (uint32_t)(seed >> 32);
+    return tsu_dense_own_run(d, 1, &rep, d->state, n_sweeps, have_uni ? d->uniforms : nullptr, order_dev, temps_dev, samples_dev, rec_from, rec_every,
+                             fields_were_valid, true, done);
+}
+
 // a whole run (burn-in, then n_samples x n_sweeps sweeps with the state recorded after each group; or an annealing schedule: one
-// temperature per sweep) in ONE pipeline launch; *done = 0: the pipeline does not take it (the caller's loop of calls does)
+// temperature per sweep) in ONE launch -- the owner-computes kernel first, then the pipeline; *done = 0: neither takes it (the
+// caller's loop of calls does).  order_dev: the caller's visiting orders ([n_total][n], owner-computes kernel only) or nullptr.
 int tsu_dense_pipe_run(tsu_dense* d, double T, const double* temps_dev, int n_total, int rec_from, int rec_every, int8_t* samples_dev,
-                       uint64_t seed, uint32_t sweep0, uint32_t replica, bool have_uni, int* done) {
+                       uint64_t seed, uint32_t sweep0, uint32_t replica, bool have_uni, int* done, const int64_t* order_dev) {
     *done = 0;
-    const bool fields_were_valid = d->fields_valid != 0;
+    bool fields_were_valid = d->fields_valid != 0;
     const int streak = d->pipe_streak;
     d->fields_valid = 0;
     d->pipe_streak = 0;
-    if (d->pp_failed || n_total <= 0) return TSU_OK;
+    if (n_total <= 0) return TSU_OK;
+    if (!d->own_failed) {
+        d->pipe_streak = streak;
+        const int rc = own_try(d, T, n_total, seed, sweep0, replica, have_uni, order_dev, temps_dev, samples_dev, rec_from, rec_every, fields_were_valid, done);
+        if (!*done) d->pipe_streak = 0;
+        if (rc != TSU_OK || *done) return rc;
+        if (d->own_failed) {  // it ran and gave up half way: back to the state at the start of the call (the caller's backup)
+            TSU_HIP_TRY(d->ctx, hipMemcpyAsync(d->state, d->backup, (size_t)d->n, hipMemcpyDeviceToDevice, d->ctx->stream));
+            fields_were_valid = false;
+        }
+    }
+    if (d->pp_failed || order_dev) return TSU_OK;
     d->pipe_streak = streak;
     const int rc = d->dtype == TSU_DTYPE_F64
                        ? pipe_sweep<double>(d, T, n_total, seed, sweep0, replica, have_uni, done, fields_were_valid, temps_dev, samples_dev, rec_from, rec_every)
@@ -1151,15 +1115,26 @@ int tsu_dense_pipe_run(tsu_dense* d, double T, const double* temps_dev, int n_to
 }
 
 int tsu_dense_coop_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint32_t sweep0, uint32_t replica, bool have_uni,
-                         int* done) {
-    // first choice: the two-role pipeline (in place on d->state); it declines small / odd systems and reports a failed
-    // run with *done = 0, in which case the caller has restored the state and the barrier kernel below takes the call
-    // (whatever happens below, the fields kept from the last pipeline call stop being those of d->state; a successful pipeline call
-    // sets the flag again)
-    const bool fields_were_valid = d->fields_valid != 0;
+                         int* done, const int64_t* order_dev) {
+    // first choice: the owner-computes kernel, then the two-role pipeline (both in place on d->state); they decline small / odd systems
+    // and report a failed run with *done = 0, in which case the state is restored here and the barrier kernel below takes the call
+    // (whatever happens below, the fields kept from the last call stop being those of d->state; a successful call sets the flag again)
+    bool fields_were_valid = d->fields_valid != 0;
     const int streak = d->pipe_streak;
     d->fields_valid = 0;
     d->pipe_streak = 0;
+    *done = 0;
+    if (!d->own_failed) {
+        d->pipe_streak = streak;
+        const int rc = own_try(d, T, n_sweeps, seed, sweep0, replica, have_uni, order_dev, nullptr, nullptr, 0, 1, fields_were_valid, done);
+        if (!*done) d->pipe_streak = 0;
+        if (rc != TSU_OK || *done) return rc;
+        if (d->own_failed) {
+            TSU_HIP_TRY(d->ctx, hipMemcpyAsync(d->state, d->backup, (size_t)d->n, hipMemcpyDeviceToDevice, d->ctx->stream));
+            fields_were_valid = false;
+        }
+    }
+    if (order_dev) return TSU_OK;  // the other one-launch kernels run in natural order only
     if (!d->pp_failed) {
         d->pipe_streak = streak;
         const int rc = d->dtype == TSU_DTYPE_F64 ? pipe_sweep<double>(d, T, n_sweeps, seed, sweep0, replica, have_uni, done, fields_were_valid)

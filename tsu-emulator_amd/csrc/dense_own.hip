@@ -1,0 +1,690 @@
+// dense_own.hip -- K2 "owner computes" (k2_own): sequential Gibbs sweeps on a dense J in ONE launch of a co-resident grid, every
+// workgroup the owner of 64 M consecutive sites for the whole call.
+//
+// Same mathematics as the other dense paths (dense_coop.hip): the sequential pass over a superblock of positions is the unique
+// fixed point of v = decide(F0 + L (v - v0)) (L = strictly lower triangle of the superblock's couplings in visiting order, v0 the
+// values at its start), reached exactly by Jacobi iteration from v = v0.  What differs is who holds what:
+//   * The FIELD of a site lives in its owner's registers (lane = site) from the first sweep to the last.  Nothing about fields ever
+//     crosses workgroups, so the only inter-workgroup traffic is the VALUE MASKS of the sites that are being decided: one 8-byte
+//     {32 values, tag} granule pair per 64 sites and generation, written with one sc1 store each and polled by whoever needs them
+//     (each granule validates itself by its tag: no counters, no barriers, no atomics).
+//   * J is read in AXPY form, one row of J^T per site whose value CHANGED: F[r] += +-J^T[j, r] for the owner's rows r (lanes are
+//     consecutive r: coalesced).  A superblock in which 41 % of the sites flip therefore reads 41 % of its strip of J, and a
+//     generation in which thirty sites toggle reads thirty row segments -- not the dot products over every column of the
+//     superblock the row-owning pipeline (k2_pipe) computes.  Summation orders are fixed (list order, then a fixed tree over the
+//     waves), so results are reproducible bit for bit.
+//   * Natural order: the owners of a superblock's sites ("active" workgroups) run the generations among themselves; everybody else
+//     waits for the superblock's FINAL masks (a ring of tagged granules) and applies the final flips to its rows in one pass.
+//   * A caller's visiting order (update_order="random": one permutation per sweep): a superblock is a range of POSITIONS, its sites
+//     are spread over all workgroups, so every workgroup is active in every superblock, follows every generation and applies every
+//     toggle to all its rows (unmasked: the running field) and to the rows that come later in the order (masked: the decision).
+//   * Replicas (tempering ladders, independent chains on ONE J): R states advance together; a row of J^T is loaded once for the
+//     union of the replicas' toggles and applied to each replica's accumulator with that replica's sign.
+#include <algorithm>
+#include <vector>
+
+#include "dense_dev.h"
+
+#define OWN_THREADS 1024
+#define OWN_WAVES (OWN_THREADS / 64)
+#define OWN_RING 8              // superblocks whose final masks are kept (a workgroup is active at least once per sweep, and cannot be
+                                // active before it has applied every earlier superblock: nobody lags more than a sweep = at most
+                                // OWN_RING superblocks, checked by the host)
+#define OWN_TAG_SPAN 16384u     // generation g of superblock number q carries tag q * SPAN + g + 1 (0 = never written)
+#define OWN_MAX_R 8
+
+struct OwnParams {
+    const void* JT;
+    const double* bias;
+    int8_t* state;               // [R][n] values, committed in place superblock by superblock
+    const double* uniforms;      // [R][n_sweeps][n] replayed uniforms (indexed by position) or nullptr
+    unsigned long long* gen;     // [2][R][G][2] granules of the running generation (two buffers by generation parity)
+    unsigned long long* fin;     // [OWN_RING][R][G][2] granules of the final values of a superblock (tag = superblock number + 1)
+    unsigned* bar;               // error words (BAR_ERR page layout of dense_dev.h)
+    const int64_t* order;        // [n_sweeps][n] visiting orders, or nullptr (natural order)
+    const double* temps;         // one temperature per sweep (R == 1), or nullptr
+    int8_t* samples;             // (R == 1) the state after sweep rec_from + m rec_every goes to samples + (m - 1) n, or nullptr
+    double* fields_all;          // (R == 1) [n] fields kept from call to call (dense.h)
+    unsigned long long* timeline;
+    int n, n_sweeps;
+    int sbw;                     // workgroups per superblock (natural order); positions per superblock = sbw * 64 M
+    int lmax;                    // toggle-list capacity (entries) = positions per superblock
+    int rec_from, rec_every, resume, persist, refresh_off;
+    OwnRep rep[OWN_MAX_R];
+};
+
+// the decision helpers of dense_dev.h with the uniform's index apart from the site (a replayed uniform belongs to the POSITION in
+// the visiting order, gibbs.py:126; the Philox uniform to the site)
+static __device__ __noinline__ int own_decide_exact(double F, double T, uint32_t site, uint32_t uidx, const double* __restrict__ uniforms,
+                                                    uint32_t sweep, uint32_t tag, uint32_t k0, uint32_t k1) {
+    const double u = uniforms ? uniforms[uidx] : dense_uniform(site, sweep, tag, k0, k1);
+    return (u < sigmoid_clamped(F / T)) ? 1 : 0;
+}
+static __device__ __forceinline__ int own_decide(double F, double lg, double T, double invT, uint32_t site, uint32_t uidx,
+                                                 const double* __restrict__ uniforms, uint32_t sweep, uint32_t tag, uint32_t k0, uint32_t k1) {
+    const double xa = F * invT;
+    if (fabs(fabs(xa) - 20.0) < 1e-9 || fabs(xa - lg) <= 1e-9 * (1.0 + fabs(lg)))
+        return own_decide_exact(F, T, site, uidx, uniforms, sweep, tag, k0, k1);
+    if (xa > 20.0) return 1;
+    if (xa < -20.0) return 0;
+    return xa > lg ? 1 : 0;
+}
+static __device__ __noinline__ double own_logit(uint32_t site, uint32_t uidx, const double* __restrict__ uniforms, uint32_t sweep, uint32_t tag,
+                                                uint32_t k0, uint32_t k1) {
+    const double u = uniforms ? uniforms[uidx] : dense_uniform(site, sweep, tag, k0, k1);
+    return log(u) - log1p(-u);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- the axpy pass
+// F[r] += sum over the list entries (site j, sign) of +-J^T[j, r] for the workgroup's 64 M rows.  A lane owns a QUAD of four
+// consecutive rows and one of the 4 / M entry slots of its wave: a wave-instruction loads 16 bytes per lane = the row segments of
+// 4 / M consecutive entries (a "bundle"; with one dword per lane the pass was bound by instruction issue, ~15 instructions per
+// entry and wave, not by memory).  Every wave takes the bundles b = wave, wave + 16, ..., U bundles in flight per lane, loads
+// unconditional (entries beyond the list read the segment of site 0 with weight 0: a predicated load becomes a branch and the loads
+// serial round trips).  At the end the entry slots are added up across the lanes (fixed order), the sixteen waves' partial sums go
+// to LDS, and the rows' owners add them up in wave order.
+//   MODE 0: every entry to every row (strips of final flips, the field pass): slots = replicas
+//   MODE 1: natural order, generations: entry j only to the rows r > j (the decision's correction): slots = replicas
+//   MODE 2: a caller's order (R = 1): slot 0 = rows later in the order than j (the correction), slot 1 = every row (the running field)
+// NA = accumulator slots of the KERNEL (the layout of `red`).
+template <typename TJ>
+struct OwnQuad;
+template <>
+struct OwnQuad<float> {
+    float4 v;
+    __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
+    __device__ __forceinline__ double get(int m) const { return (double)(m == 0 ? v.x : m == 1 ? v.y : m == 2 ? v.z : v.w); }
+};
+template <>
+struct OwnQuad<double> {
+    double2 a, b;
+    __device__ __forceinline__ void load(const double* p) {
+        a = *reinterpret_cast<const double2*>(p);
+        b = *reinterpret_cast<const double2*>(p + 2);
+    }
+    __device__ __forceinline__ double get(int m) const { return m == 0 ? a.x : m == 1 ? a.y : m == 2 ? b.x : b.y; }
+};
+
+template <typename TJ, int M, int R, int MODE, int NA>
+static __device__ __forceinline__ void own_axpy(const TJ* __restrict__ JT, int n, const uint32_t* lst, int nl, int col0, int myrow,
+                                                const unsigned short* pos, const int* mypos, double* red, int lane, int wv) {
+    constexpr int QL = 16 * M;   // quads (lanes) per entry slot
+    constexpr int ES = 4 / M;    // entry slots per wave-instruction
+    constexpr int NS = MODE == 2 ? 2 : R;
+    constexpr int U = (sizeof(TJ) == 8 || R >= 4) ? 4 : 8;
+    const int t = lane / QL;     // my entry slot
+    double acc[NS][4];
+#pragma unroll
+    for (int a = 0; a < NS; ++a)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[a][m] = 0.0;
+    const int nb = (nl + ES - 1) / ES;  // bundles
+    for (int b = wv; b < nb; b += OWN_WAVES * U) {
+        OwnQuad<TJ> x[U];
+        uint32_t e[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = (b + OWN_WAVES * u) * ES + t;
+            e[u] = k < nl ? lst[k] : 0u;
+            x[u].load(JT + (size_t)(e[u] & 0xFFFFu) * n + col0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t ev = e[u];
+            const int j = (int)(ev & 0xFFFFu);
+            const uint32_t code = ev >> 16;
+            double v[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) v[m] = x[u].get(m);
+            if (MODE == 2) {
+                const double sg = (code & 1u) ? ((code & 2u) ? -1.0 : 1.0) : 0.0;
+                const int pj = pos[j];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const double sv = sg * v[m];
+                    acc[1][m] += sv;
+                    acc[0][m] += pj < mypos[m] ? sv : 0.0;
+                }
+            } else {
+                if (MODE == 1) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) v[m] = j < myrow + m ? v[m] : 0.0;
+                }
+#pragma unroll
+                for (int rho = 0; rho < R; ++rho) {
+                    const uint32_t c = (code >> (2 * rho)) & 3u;
+                    const double sg = (c & 1u) ? ((c & 2u) ? -1.0 : 1.0) : 0.0;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc[rho][m] += sg * v[m];
+                }
+            }
+        }
+    }
+    // the entry slots of a quad: lanes q, q + QL, ... (fixed order: ((0 + 1) + (2 + 3)))
+#pragma unroll
+    for (int a = 0; a < NS; ++a)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            double z = acc[a][m];
+            if (ES >= 2) z += __shfl_xor(z, QL, 64);
+            if (ES >= 4) z += __shfl_xor(z, 2 * QL, 64);
+            acc[a][m] = z;
+        }
+    if (lane < QL) {
+#pragma unroll
+        for (int a = 0; a < NS; ++a)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) red[(wv * NA + a) * (64 * M) + 4 * lane + m] = acc[a][m];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ the kernel
+template <typename TJ, int M, int R, bool ORD>
+__global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
+    static_assert(!ORD || R == 1, "replicas advance in natural order only");
+    constexpr int RW = 64 * M;           // sites per workgroup
+    constexpr int NA = ORD ? 2 : R;      // accumulator slots of the axpy pass
+    constexpr int PW = M;                // the wave that polls and builds the lists (the first one that owns no rows)
+    extern __shared__ unsigned long long own_lds[];
+    __shared__ int s_nl, s_nle, s_fail;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int w = (int)blockIdx.x, W = (int)gridDim.x, G = W * M;
+    const int n = P.n;
+    const TJ* __restrict__ JT = (const TJ*)P.JT;
+    const int NP = ORD ? G : P.sbw * M;   // groups per exchange, at most
+    const int LMAX = P.lmax;
+    unsigned long long* vmask = own_lds;        // [R][G]   committed values of every site, 64 per group
+    unsigned long long* gm = vmask + R * G;     // [R][NP]  values of the running generation (the polled groups)
+    unsigned long long* nm = gm + R * NP;       // [R][NP]  masks just polled
+    double* red = (double*)(nm + R * NP);       // [OWN_WAVES][NA][M][64]
+    uint32_t* lst = (uint32_t*)(red + OWN_WAVES * NA * M * 64);  // [LMAX] site | codes << 16 (per replica: bit 0 toggled, bit 1 value now 0)
+    double* dF = (double*)(lst + LMAX);         // [R][M][64] the owners' state, in LDS so that it does not occupy registers of every wave:
+    double* dC = dF + R * M * 64;               //   field at the start of the superblock, correction of the running generation,
+    double* dL = dC + R * M * 64;               //   logit of the uniform,
+    double* dA = dL + R * M * 64;               //   (ORD) the running field's change inside the current superblock  [M][64]
+    unsigned short* pos = (unsigned short*)(dA + M * 64);        // (ORD) [n] position of every site in this sweep's order
+#define OWN_AT(rho) (((rho) * M + wv) * 64 + lane)
+
+    const int r0 = w * RW;
+    const int myrow = r0 + 4 * (lane % (16 * M));       // the axpy pass: this lane's quad of rows myrow .. myrow + 3
+    const int col0 = myrow + 4 <= n ? myrow : n - 4;    // (n is a multiple of 4: whole quads; lanes beyond n read the last one, unused)
+    const bool decider = wv < M;                        // wave e < M, lane l decides site r0 + 64 e + l
+    const int site = r0 + 64 * (decider ? wv : 0) + lane;
+    const bool site_ok = decider && site < n;
+    const int mygroup = w * M + (decider ? wv : 0);
+    if (threadIdx.x == 0) s_fail = 0;
+
+    const bool timing = P.timeline && (int)blockIdx.x == W - 1 && threadIdx.x == 0;
+    unsigned long long tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tl_last = wall_clock64();
+#define OWN_MARK(kind)                                    \
+    if (timing) {                                         \
+        const long long now_ = wall_clock64();            \
+        tl[kind] += (unsigned long long)(now_ - tl_last); \
+        tl_last = now_;                                   \
+    }
+
+    // ---- committed values of every site as bit masks (one per 64-site group), in every workgroup
+    for (int q = wv; q < R * G; q += OWN_WAVES) {
+        const int rho = q / G, g = q - rho * G;
+        const int sj = 64 * g + lane;
+        const int b = sj < n ? (int)P.state[(size_t)rho * n + sj] : 0;
+        const unsigned long long mk = __ballot(b != 0);
+        if (lane == 0) vmask[q] = mk;
+    }
+    __syncthreads();
+
+    // ---- the poller wave's tools -------------------------------------------------------------------------------------------
+    // poll the granules of groups [g_lo, g_lo + np) of every replica in `buf` until all carry `tag`; the masks go to nm
+    auto poll = [&](const unsigned long long* buf, unsigned tag, int g_lo, int np, bool sleepy) {
+        for (int k0 = 0; k0 < np; k0 += 64) {
+            const int k = k0 + lane;
+            const bool okk = k < np;
+            const unsigned long long* p = buf + (size_t)(g_lo + (okk ? k : 0)) * 2;
+            unsigned long long lo[R], hi[R];
+            const long long t0 = wall_clock64();
+            for (unsigned spins = 0;; ++spins) {
+                bool all = true;
+#pragma unroll
+                for (int rho = 0; rho < R; ++rho) {
+                    lo[rho] = ld(p + (size_t)rho * G * 2);
+                    hi[rho] = ld(p + (size_t)rho * G * 2 + 1);
+                    all = all && (unsigned)(lo[rho] >> 32) == tag && (unsigned)(hi[rho] >> 32) == tag;
+                }
+                if (__ballot(okk && !all) == 0ull) break;
+                if (sleepy) __builtin_amdgcn_s_sleep(16);
+                if ((spins & 63u) == 63u) {
+                    if (ld(&P.bar[BAR_ERR]) || wall_clock64() - t0 > CO_TIMEOUT) {
+                        st(&P.bar[BAR_ERR], 1u);
+                        s_fail = 1;
+                        break;
+                    }
+                }
+            }
+            if (okk) {
+#pragma unroll
+                for (int rho = 0; rho < R; ++rho) nm[rho * NP + k] = (lo[rho] & 0xFFFFFFFFull) | (hi[rho] << 32);
+            }
+        }
+    };
+    // list of the sites whose value differs between newp[rho * sn + k] and oldp[rho * so + k] (oldp == nullptr: all zero), k < np,
+    // group g_lo + k, ascending; with write_back the old masks become the new ones.  s_nl = entries, s_nle = entries up to and
+    // including this workgroup's own groups (natural order: later sites never enter a correction).
+    auto build_list = [&](const unsigned long long* newp, int sn, unsigned long long* oldp, int so, int g_lo, int np, bool write_back) {
+        int base = 0;
+        if (lane == 0) s_nle = 0;
+        for (int k0 = 0; k0 < np; k0 += 64) {
+            const int k = k0 + lane;
+            const bool okk = k < np;
+            unsigned long long nw[R], tg[R], un = 0ull;
+#pragma unroll
+            for (int rho = 0; rho < R; ++rho) {
+                nw[rho] = okk ? newp[rho * sn + k] : 0ull;
+                const unsigned long long ol = (okk && oldp) ? oldp[rho * so + k] : 0ull;
+                tg[rho] = nw[rho] ^ ol;
+                un |= tg[rho];
+                if (write_back && okk) oldp[rho * so + k] = nw[rho];
+            }
+            const int pc = __popcll(un);
+            int off = pc;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                const int v = __shfl_up(off, dd, 64);
+                if (lane >= dd) off += v;
+            }
+            const int total = __shfl(off, 63, 64);
+            off = base + off - pc;
+            const int g = g_lo + k;
+            const int sbase = 64 * g;
+            while (un) {
+                const int b = __ffsll((long long)un) - 1;
+                un &= un - 1ull;
+                uint32_t code = 0u;
+#pragma unroll
+                for (int rho = 0; rho < R; ++rho)
+                    if ((tg[rho] >> b) & 1ull) code |= (1u | (((nw[rho] >> b) & 1ull) ? 0u : 2u)) << (2 * rho);
+                lst[off++] = (uint32_t)(sbase + b) | (code << 16);
+            }
+            if (okk && g == w * M + M - 1) s_nle = off;
+            base += total;
+        }
+        if (lane == 0) s_nl = base;
+    };
+
+    // (natural order) the workgroups that decide the NEXT superblock need its predecessor's flips first: everybody else holds its own
+    // strip back until their first generation is out (a hint only -- bounded, nothing depends on it: 30 us at most)
+    auto yield_to_next = [&](unsigned seq_now, int sb_now, int sw_now) {
+        const int nsb_ = (W + P.sbw - 1) / P.sbw;
+        const int sbn = sb_now + 1 < nsb_ ? sb_now + 1 : 0;
+        if (nsb_ < 2 || w / P.sbw == sbn || (sbn == 0 && sw_now + 1 >= P.n_sweeps)) return;
+        if (lane == 0) {
+            const int gl = ((sbn + 1) * P.sbw * M < G ? (sbn + 1) * P.sbw * M : G) - 1;
+            const unsigned long long* p = P.gen + (size_t)gl * 2;  // generation parity 0, replica 0
+            const unsigned want = (seq_now + 1u) * OWN_TAG_SPAN + 1u;
+            const long long t0 = wall_clock64();
+            while ((unsigned)(ld(p) >> 32) < want && wall_clock64() - t0 < 3000) __builtin_amdgcn_s_sleep(32);
+        }
+    };
+
+    // ---- the rows' owners: field, correction, logit and committed value per replica ------------------------------------------
+    int vcur = 0;    // committed value of my site, bit rho
+    if (decider) {
+#pragma unroll
+        for (int rho = 0; rho < R; ++rho) {
+            dF[OWN_AT(rho)] = 0.0;
+            dC[OWN_AT(rho)] = 0.0;
+            dL[OWN_AT(rho)] = 0.0;
+            vcur |= (int)((vmask[rho * G + mygroup] >> lane) & 1ull) << rho;
+        }
+        dA[wv * 64 + lane] = 0.0;
+    }
+    int mypos[4];  // (ORD) positions of this lane's axpy rows
+#pragma unroll
+    for (int m = 0; m < 4; ++m) mypos[m] = 0;
+    int dpos = site;  // position of my site in the visiting order (deciders)
+    // owners add the sixteen waves' partial sums of slot a in wave order
+    auto reduced = [&](int a) -> double {
+        double tot = 0.0;
+#pragma unroll
+        for (int u = 0; u < OWN_WAVES; ++u) tot += red[(u * NA + a) * RW + 64 * wv + lane];
+        return tot;
+    };
+
+    const int nsb = ORD ? (n + P.sbw * RW - 1) / (P.sbw * RW) : (W + P.sbw - 1) / P.sbw;
+    unsigned seq = 0;  // superblocks so far
+    for (int sw = 0; sw < P.n_sweeps; ++sw) {
+        if (ORD) {
+            const int64_t* ord = P.order + (size_t)sw * n;
+            for (int p = (int)threadIdx.x; p < n; p += OWN_THREADS) pos[ord[p]] = (unsigned short)p;
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < 4; ++m) mypos[m] = myrow + m < n ? (int)pos[myrow + m] : 0x7FFFFFFF;
+            dpos = site_ok ? (int)pos[site] : 0x7FFFFFFF;
+        }
+        // a sweep starts from complete fields: computed from scratch every CO_REFRESH sweeps (counted across calls) and at the start
+        // of a call -- unless the previous call left them (resume) -- and kept current by the axpy passes in between
+        const bool start_phase = sw == 0 || ((sw + P.refresh_off) % CO_REFRESH) == 0;
+        if (start_phase) {
+            if (sw == 0 && P.resume) {
+                if (site_ok) dF[OWN_AT(0)] = P.fields_all[site];
+            } else {
+                if (decider) {
+#pragma unroll
+                    for (int rho = 0; rho < R; ++rho) dF[OWN_AT(rho)] = (site_ok && P.bias) ? P.bias[site] : 0.0;
+                }
+                const int lch = LMAX / 64;  // groups per list
+                for (int g0 = 0; g0 < G; g0 += lch) {
+                    const int np = G - g0 < lch ? G - g0 : lch;
+                    if (wv == PW) build_list(vmask + g0, G, nullptr, 0, g0, np, false);
+                    __syncthreads();
+                    const int nl = s_nl;
+                    own_axpy<TJ, M, R, 0, NA>(JT, n, lst, nl, col0, myrow, pos, mypos, red, lane, wv);
+                    __syncthreads();
+                    if (decider) {
+#pragma unroll
+                        for (int rho = 0; rho < R; ++rho) dF[OWN_AT(rho)] += reduced(rho);
+                    }
+                    __syncthreads();  // red and the list are rewritten
+                }
+            }
+        }
+        for (int sb = 0; sb < nsb; ++sb, ++seq) {
+            const bool active = ORD || w / P.sbw == sb;
+            const int g_lo = ORD ? 0 : sb * P.sbw * M;
+            const int np = ORD ? G : (G - g_lo < NP ? G - g_lo : NP);
+            const int p0 = sb * P.sbw * RW, p1 = p0 + P.sbw * RW;  // (ORD) positions of the superblock
+            const unsigned slot = seq % OWN_RING;
+            if (active) {
+                const bool mine = site_ok && (!ORD || (dpos >= p0 && dpos < p1));  // my site is decided in this superblock
+                double Tw[R], invT[R];
+                const double* uni[R];
+                uint32_t tt[R];
+#pragma unroll
+                for (int rho = 0; rho < R; ++rho) {
+                    Tw[rho] = P.temps ? P.temps[sw] : P.rep[rho].T;
+                    invT[rho] = 1.0 / Tw[rho];
+                    uni[rho] = P.uniforms ? P.uniforms + ((size_t)rho * P.n_sweeps + sw) * n : nullptr;
+                    tt[rho] = P.rep[rho].sweep0 + (uint32_t)sw;
+                    if (mine) dL[OWN_AT(rho)] = own_logit((uint32_t)site, (uint32_t)dpos, uni[rho], tt[rho], P.rep[rho].tag, P.rep[rho].k0, P.rep[rho].k1);
+                    if (decider) dC[OWN_AT(rho)] = 0.0;
+                }
+                if (decider) dA[wv * 64 + lane] = 0.0;
+                // the running generation starts from the committed values
+                for (int q = (int)threadIdx.x; q < R * np; q += OWN_THREADS) {
+                    const int rho = q / np, k = q - rho * np;
+                    gm[rho * NP + k] = vmask[rho * G + g_lo + k];
+                }
+                __syncthreads();
+                int vnew = vcur;
+                unsigned gi = 0;
+                OWN_MARK(0);
+                while (true) {
+                    const unsigned tag = seq * OWN_TAG_SPAN + gi + 1u;
+                    unsigned long long* gbuf = P.gen + (size_t)(gi & 1u) * R * G * 2;
+                    if (decider) {
+#pragma unroll
+                        for (int rho = 0; rho < R; ++rho) {
+                            int v = (vcur >> rho) & 1;
+                            if (mine)
+                                v = own_decide(dF[OWN_AT(rho)] + dC[OWN_AT(rho)], dL[OWN_AT(rho)], Tw[rho], invT[rho], (uint32_t)site, (uint32_t)dpos, uni[rho], tt[rho], P.rep[rho].tag,
+                                               P.rep[rho].k0, P.rep[rho].k1);
+                            vnew = (vnew & ~(1 << rho)) | (v << rho);
+                            const unsigned long long mk = __ballot(v != 0);
+                            if (lane < 2)
+                                st(gbuf + ((size_t)rho * G + mygroup) * 2 + lane, ((mk >> (32 * lane)) & 0xFFFFFFFFull) | ((unsigned long long)tag << 32));
+                        }
+                    }
+                    if (wv == PW) {
+                        poll(gbuf, tag, g_lo, np, false);
+                        build_list(nm, NP, gm, NP, g_lo, np, true);
+                    }
+                    __syncthreads();
+                    if (s_fail) return;
+                    const int nl = s_nl;
+                    OWN_MARK(1);
+                    if (timing) {
+                        tl[4] += 1;
+                        tl[5] += (unsigned long long)nl;
+                    }
+                    if (nl == 0) break;  // nobody's value changed: the fixed point
+                    if (ORD) own_axpy<TJ, M, R, 2, NA>(JT, n, lst, nl, col0, myrow, pos, mypos, red, lane, wv);
+                    else own_axpy<TJ, M, R, 1, NA>(JT, n, lst, s_nle, col0, myrow, pos, mypos, red, lane, wv);
+                    __syncthreads();
+                    if (decider) {
+                        if (ORD) {
+                            dC[OWN_AT(0)] += reduced(0);
+                            dA[wv * 64 + lane] += reduced(1);
+                        } else {
+#pragma unroll
+                            for (int rho = 0; rho < R; ++rho) dC[OWN_AT(rho)] += reduced(rho);
+                        }
+                    }
+                    ++gi;
+                    if (gi + 2u >= OWN_TAG_SPAN) {  // cannot happen (the iteration is exact after as many generations as the superblock has positions)
+                        if (threadIdx.x == 0) st(&P.bar[BAR_ERR + 2], 1u);
+                        return;
+                    }
+                    OWN_MARK(2);
+                }
+                __syncthreads();  // (every wave has read s_nl before the poller writes it again)
+                // converged: gm holds the final values.  Commit my site, publish the final masks for the workgroups that did not follow
+                int8_t* rec = nullptr;
+                if (P.samples && sw + 1 > P.rec_from && (sw + 1 - P.rec_from) % P.rec_every == 0)
+                    rec = P.samples + (size_t)((sw + 1 - P.rec_from) / P.rec_every - 1) * n;
+                if (decider) {
+#pragma unroll
+                    for (int rho = 0; rho < R; ++rho) {
+                        const int v = (vnew >> rho) & 1;
+                        if (mine) {
+                            P.state[(size_t)rho * n + site] = (int8_t)v;
+                            if (rec) rec[site] = (int8_t)v;
+                        }
+                        if (!ORD) {
+                            const unsigned long long mk = __ballot(v != 0);
+                            if (lane < 2)
+                                st(P.fin + (((size_t)slot * R + rho) * G + mygroup) * 2 + lane,
+                                   ((mk >> (32 * lane)) & 0xFFFFFFFFull) | ((unsigned long long)(seq + 1u) << 32));
+                        }
+                    }
+                    vcur = vnew;
+                }
+                if (ORD) {
+                    // every workgroup followed every generation: the running field is current
+                    if (decider) dF[OWN_AT(0)] += dA[wv * 64 + lane];
+                    for (int q = (int)threadIdx.x; q < np; q += OWN_THREADS) vmask[q] = gm[q];
+                    __syncthreads();
+                } else {
+                    // my rows' fields: the superblock's final flips in one pass (every entry, unmasked; the correction is dropped)
+                    if (wv == PW) {
+                        build_list(gm, NP, vmask + g_lo, G, g_lo, np, true);
+                        yield_to_next(seq, sb, sw);
+                    }
+                    __syncthreads();
+                    const int nl = s_nl;
+                    own_axpy<TJ, M, R, 0, NA>(JT, n, lst, nl, col0, myrow, pos, mypos, red, lane, wv);
+                    __syncthreads();
+                    if (decider) {
+#pragma unroll
+                        for (int rho = 0; rho < R; ++rho) dF[OWN_AT(rho)] += reduced(rho);
+                    }
+                    __syncthreads();
+                }
+                OWN_MARK(3);
+            } else {
+                // not my superblock: wait for its final values, apply the flips to my rows
+                OWN_MARK(0);
+                if (wv == PW) {
+                    poll(P.fin + (size_t)slot * R * G * 2, seq + 1u, g_lo, np, true);
+                    build_list(nm, NP, vmask + g_lo, G, g_lo, np, true);
+                    yield_to_next(seq, sb, sw);
+                }
+                __syncthreads();
+                if (s_fail) return;
+                OWN_MARK(6);
+                const int nl = s_nl;
+                own_axpy<TJ, M, R, 0, NA>(JT, n, lst, nl, col0, myrow, pos, mypos, red, lane, wv);
+                __syncthreads();
+                if (decider) {
+#pragma unroll
+                    for (int rho = 0; rho < R; ++rho) dF[OWN_AT(rho)] += reduced(rho);
+                }
+                __syncthreads();
+                OWN_MARK(7);
+            }
+        }
+    }
+    if (P.persist && site_ok) P.fields_all[site] = dF[OWN_AT(0)];
+    if (timing)
+        for (int x = 0; x < 8; ++x) P.timeline[x] = tl[x];
+#undef OWN_MARK
+#undef OWN_AT
+}
+
+// ---------------------------------------------------------------------------------------------------------------------- host side
+typedef void (*own_kern)(OwnParams);
+
+template <typename TJ>
+static own_kern own_pick(int M, int R, bool ord) {
+    if (ord) return M == 1 ? k2_own<TJ, 1, 1, true> : M == 2 ? k2_own<TJ, 2, 1, true> : k2_own<TJ, 4, 1, true>;
+    if (R == 1) return M == 1 ? k2_own<TJ, 1, 1, false> : M == 2 ? k2_own<TJ, 2, 1, false> : k2_own<TJ, 4, 1, false>;
+    if (M != 1) return nullptr;
+    return R == 2 ? k2_own<TJ, 1, 2, false> : R == 4 ? k2_own<TJ, 1, 4, false> : R == 8 ? k2_own<TJ, 1, 8, false> : nullptr;
+}
+
+static int own_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+// One launch of k2_own: n_sweeps sweeps of R states.  *done = 0: the kernel does not take this call (the caller's other paths do;
+// nothing was written) or it gave up half way (d->own_failed set: the caller restores the state from its backup).
+//   states_dev: [R][n] device states (R == 1: d->state), uniforms_dev: [R][n_sweeps][n] or nullptr, order_dev: [n_sweeps][n] or nullptr
+int tsu_dense_own_run(tsu_dense* d, int R_real, const OwnRep* reps, int8_t* states_dev, int n_sweeps, const double* uniforms_dev,
+                      const int64_t* order_dev, const double* temps_dev, int8_t* samples_dev, int rec_from, int rec_every, bool fields_were_valid,
+                      bool allow_persist, int* done) {
+    tsu_ctx* ctx = d->ctx;
+    const int n = d->n;
+    *done = 0;
+    static const int use_own = own_env("TSU_K2_OWN", 1);
+    static const int own_min = own_env("TSU_K2_OWN_MIN", 2048);
+    static const int sb_env = own_env("TSU_K2_OWN_SB", 0);
+    if (!use_own || d->own_failed || n < own_min || n > 65536 || n_sweeps <= 0) return TSU_OK;
+    const bool ord = order_dev != nullptr;
+    if (R_real < 1 || R_real > OWN_MAX_R || (ord && R_real != 1)) return TSU_OK;
+    const int R = R_real == 1 ? 1 : R_real == 2 ? 2 : R_real <= 4 ? 4 : 8;
+    int M = 0;
+    for (int m = 1; m <= 4; m *= 2)
+        if ((n + 64 * m - 1) / (64 * m) <= ctx->cus) {
+            M = m;
+            break;
+        }
+    if (!M || (R > 1 && M != 1) || n % 4) return TSU_OK;  // (rows travel as quads)
+    const int RW = 64 * M, W = (n + RW - 1) / RW, G = W * M;
+    if (W < 2) return TSU_OK;
+    int sb = sb_env > 0 ? sb_env : 4096;
+    if (sb < RW) sb = RW;
+    if (sb > 8192) sb = 8192;
+    int sbw = sb / RW;
+    if (sbw > W) sbw = W;
+    const int lmax = sbw * RW;
+    const int nsb = ord ? (n + sbw * RW - 1) / (sbw * RW) : (W + sbw - 1) / sbw;
+    if (!ord && nsb > OWN_RING) return TSU_OK;
+    if ((long long)n_sweeps * nsb >= (long long)(0xFFFFFFFFu / OWN_TAG_SPAN) - 2) return TSU_OK;  // generation tags are 32 bits
+    const int NP = ord ? G : sbw * M, NA = ord ? 2 : R;
+    const size_t lds_bytes = ((size_t)8 * (R * G + 2 * R * NP) + (size_t)8 * OWN_WAVES * NA * M * 64 + (size_t)4 * lmax + (size_t)8 * (3 * R + 1) * M * 64 + (ord ? (size_t)2 * n : 0) + 15) / 16 * 16;
+    if (lds_bytes > 150 * 1024) return TSU_OK;
+    own_kern kern = d->dtype == TSU_DTYPE_F64 ? own_pick<double>(M, R, ord) : own_pick<float>(M, R, ord);
+    if (!kern) return TSU_OK;
+    if (tsu_func_allow_lds(ctx, (const void*)kern, (int)lds_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return TSU_OK;
+    }
+    int per_cu = 0;
+    if (tsu_func_blocks_per_cu(ctx, (const void*)kern, OWN_THREADS, lds_bytes, &per_cu) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        return TSU_OK;
+    }
+    const size_t gen_words = (size_t)2 * R * G * 2, fin_words = (size_t)OWN_RING * R * G * 2;
+    if (d->own_cap < gen_words + fin_words) {
+        if (d->own_gran) (void)hipFree(d->own_gran);
+        d->own_gran = nullptr;
+        d->own_cap = 0;
+        TSU_HIP_TRY(ctx, hipMalloc(&d->own_gran, (gen_words + fin_words) * 8));
+        d->own_cap = gen_words + fin_words;
+    }
+    if (!d->co_bar) TSU_HIP_TRY(ctx, hipMalloc(&d->co_bar, BAR_WORDS * sizeof(unsigned)));
+    if (!d->co_fields) TSU_HIP_TRY(ctx, hipMalloc(&d->co_fields, (size_t)n * 8));
+    TSU_HIP_TRY(ctx, hipMemsetAsync(d->own_gran, 0, (gen_words + fin_words) * 8, ctx->stream));
+    TSU_HIP_TRY(ctx, hipMemsetAsync(d->co_bar + BAR_ERR, 0, 4 * sizeof(unsigned), ctx->stream));
+    OwnParams P;
+    memset(&P, 0, sizeof(P));
+    P.JT = d->JT;
+    P.bias = d->bias;
+    P.state = states_dev;
+    P.uniforms = uniforms_dev;
+    P.gen = d->own_gran;
+    P.fin = d->own_gran + gen_words;
+    P.bar = d->co_bar;
+    P.order = order_dev;
+    P.temps = temps_dev;
+    P.samples = samples_dev;
+    P.fields_all = d->co_fields;
+    P.n = n;
+    P.n_sweeps = n_sweeps;
+    P.sbw = sbw;
+    P.lmax = lmax;
+    P.rec_from = rec_from;
+    P.rec_every = rec_every > 0 ? rec_every : 1;
+    for (int r = 0; r < R; ++r) P.rep[r] = reps[r < R_real ? r : 0];  // (padding replicas repeat replica 0 on its own state copy: see the caller)
+    static const int keep_fields = own_env("TSU_K2_KEEP_FIELDS", 1);
+    const bool single = R_real == 1 && allow_persist;
+    P.resume = single && keep_fields && fields_were_valid && (d->since_refresh % CO_REFRESH) != 0 ? 1 : 0;
+    P.refresh_off = P.resume ? d->since_refresh : 0;
+    P.persist = single && keep_fields && d->pipe_streak >= 1 ? 1 : 0;
+    static const int verbose = own_env("TSU_K2_VERBOSE", 0);
+    unsigned long long* d_tl = nullptr;
+    if (verbose >= 2) {
+        TSU_HIP_TRY(ctx, hipMalloc(&d_tl, 8 * sizeof(unsigned long long)));
+        TSU_HIP_TRY(ctx, hipMemsetAsync(d_tl, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    }
+    P.timeline = d_tl;
+    {
+        const int rcx = tsu_grid_exclusive_begin(ctx);
+        if (rcx != TSU_OK) return rcx;
+    }
+    hipError_t e = tsu_launch_grid_sync(ctx, (const void*)kern, dim3((unsigned)W), dim3(OWN_THREADS), &P, lds_bytes, ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (d_tl) (void)hipFree(d_tl);
+        return TSU_OK;
+    }
+    {
+        const int rcx = tsu_grid_exclusive_end(ctx);
+        if (rcx != TSU_OK) return rcx;
+    }
+    unsigned h[4];
+    TSU_HIP_TRY(ctx, hipMemcpyAsync(h + 1, d->co_bar + BAR_ERR, 3 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (d_tl) {
+        unsigned long long tl[8];
+        (void)hipMemcpy(tl, d_tl, sizeof(tl), hipMemcpyDeviceToHost);
+        (void)hipFree(d_tl);
+        const double per = (double)n_sweeps * (ord ? nsb : 1);  // the timed workgroup is active once per sweep in natural order
+        fprintf(stderr, "[tsu] k2_own n=%d R=%d M=%d %s, superblocks of %d, %d sweeps; last workgroup, per active superblock: prologue %.1f us, polls %.1f us, "
+                        "axpy+decide %.1f us, commit+strip %.1f us, %.1f generations, %.0f toggles; per sweep as a bystander: wait %.1f us, strips %.1f us\n",
+                n, R, M, ord ? "caller's order" : "natural order", sbw * RW, n_sweeps, tl[0] / 100.0 / per, tl[1] / 100.0 / per, tl[2] / 100.0 / per,
+                tl[3] / 100.0 / per, tl[4] / per, tl[5] / per, tl[6] / 100.0 / n_sweeps, tl[7] / 100.0 / n_sweeps);
+    }
+    if (h[1] || h[3]) {
+        fprintf(stderr, "[tsu] dense sweep (owner kernel): %s; continuing on the other paths\n", h[1] ? "a wait timed out (GPU shared?)" : "no fixed point");
+        d->own_failed = 1;
+        return TSU_OK;
+    }
+    *done = 1;
+    if (R_real == 1 && allow_persist) {
+        d->since_refresh = (P.refresh_off + n_sweeps) % CO_REFRESH;
+        d->fields_valid = P.persist;
+        d->pipe_streak += 1;
+    }
+    return TSU_OK;
+}

@@ -17,6 +17,8 @@ the kernel (it serves a different class of inputs) and is never taken for a quad
 from dataclasses import dataclass
 from typing import Callable, Optional
 
+import os
+
 import numpy as np
 
 from . import _hip
@@ -78,40 +80,75 @@ class QuadraticEnergy:
         return self.k * (np.asarray(x, dtype=np.float64) - self.mu)
 
 
+_PROBE_FULL_MAX = 4096  # up to this dimension every coordinate is probed (2 d + 1 evaluations of O(d) work each)
+
+
+def _verify_quadratic(energy_fn: Callable, cand: QuadraticEnergy, x0: np.ndarray) -> bool:
+    """The candidate must reproduce the callable on random points (every coordinate moves in each of them)."""
+    rng = np.random.RandomState(12345)  # private stream: probing must not disturb the caller's np.random
+    scale = 1.0 + np.abs(x0)
+    for _ in range(6):
+        xt = x0 + rng.normal(size=x0.size) * 3.0 * scale
+        want, got = float(energy_fn(xt.copy())), cand(xt)
+        if not abs(want - got) <= 1e-9 * max(1.0, abs(want)):
+            return False
+    return True
+
+
 def _recognise_quadratic(energy_fn: Callable, x_init: np.ndarray) -> Optional[QuadraticEnergy]:
-    """Probe a callable with 2d+1 evaluations, fit a separable quadratic and verify it on random points.
-    Returns None unless the fit is exact to ~1e-9 relative (so non-quadratic energies never take the GPU path)."""
+    """Probe a callable, fit a separable quadratic and verify it on random points.  Returns None unless the fit is exact to
+    ~1e-9 relative (so non-quadratic energies never take the GPU path).
+
+    d <= 4096: every coordinate is probed (2 d + 1 evaluations).  Larger d (the README idiom ``lambda x: (x**2).sum()`` at
+    dim = 2**20): a bounded probe -- 64 random coordinates; if they agree on ONE stiffness and ONE centre, the uniform quadratic
+    is verified on random points, in which all d coordinates move, so a single deviating coordinate fails the check.  About 140
+    evaluations whatever d is.  Non-uniform separable quadratics of that size need a ``QuadraticEnergy`` descriptor."""
     if isinstance(energy_fn, QuadraticEnergy):
         return energy_fn
     x0 = np.atleast_1d(np.asarray(x_init, dtype=np.float64))
     d = x0.size
-    if d > 4096:  # probing costs O(d) calls of O(d) work each; big problems should pass a descriptor
-        return None
     try:
         e0 = float(energy_fn(x0.copy()))
-        k = np.zeros(d)
-        g = np.zeros(d)
         step = 0.5
-        for i in range(d):
+
+        def probe(i):
             xp, xm = x0.copy(), x0.copy()
             xp[i] += step
             xm[i] -= step
             ep, em = float(energy_fn(xp)), float(energy_fn(xm))
-            k[i] = (ep - 2 * e0 + em) / step ** 2
-            g[i] = (ep - em) / (2 * step)
-        if not np.all(np.isfinite(k)) or np.any(k <= 0):
-            return None
-        mu = x0 - g / k
-        c = e0 - float(np.sum(0.5 * k * (x0 - mu) ** 2))
-        cand = QuadraticEnergy(k, mu, c)
-        rng = np.random.RandomState(12345)  # private stream: probing must not disturb the caller's np.random
-        scale = 1.0 + np.abs(x0)
-        for _ in range(6):
-            xt = x0 + rng.normal(size=d) * 3.0 * scale
-            want, got = float(energy_fn(xt.copy())), cand(xt)
-            if not abs(want - got) <= 1e-9 * max(1.0, abs(want)):
+            return (ep - 2 * e0 + em) / step ** 2, (ep - em) / (2 * step)
+
+        if d <= _PROBE_FULL_MAX:
+            kg = np.array([probe(i) for i in range(d)])
+            k, g = kg[:, 0], kg[:, 1]
+            if not np.all(np.isfinite(k)) or np.any(k <= 0):
                 return None
-        return cand
+            mu = x0 - g / k
+        else:
+            idx = np.random.RandomState(54321).choice(d, size=64, replace=False)
+            kg = np.array([probe(int(i)) for i in idx])
+            ks, gs = kg[:, 0], kg[:, 1]
+            if not np.all(np.isfinite(ks)) or np.any(ks <= 0):
+                return None
+            mus = x0[idx] - gs / ks
+            # (second differences of a sum of d terms carry rounding of the order eps * |E| / step^2: hence the loose agreement
+            # test here; the verification below is what admits the candidate)
+            tol = 1e-6 * max(1.0, abs(e0)) / step ** 2
+            if np.ptp(ks) > tol or np.ptp(mus) > tol * max(1.0, 1.0 / float(np.min(ks))):
+                return None
+            kbar = float(np.median(ks))
+            kr = round(kbar * 1024) / 1024  # stiffnesses people write are short binary fractions: take the exact one if it fits
+            if abs(kr - kbar) <= tol and kr > 0:
+                kbar = kr
+            mbar = float(np.median(mus))
+            mr = round(mbar * 1024) / 1024
+            if abs(mr - mbar) <= tol * max(1.0, 1.0 / kbar):
+                mbar = mr
+            k, mu = np.float64(kbar), np.float64(mbar)
+        kf, mf = np.broadcast_to(k, (d,)), np.broadcast_to(mu, (d,))
+        c = e0 - float(np.sum(0.5 * kf * (x0 - mf) ** 2))
+        cand = QuadraticEnergy(k, mu, c)
+        return cand if _verify_quadratic(energy_fn, cand, x0) else None
     except Exception:
         return None
 
@@ -200,7 +237,17 @@ class ThermalSamplingUnit:
         if q is not None:
             return self._sample_quadratic_device(q, x_init, n_samples, return_trajectory)
 
-        # arbitrary Python energy: the reference algorithm as written (host by necessity, see module docstring)
+        # arbitrary Python energy: the reference algorithm as written (host by necessity, see module docstring): finite differences
+        # with 2 d energy calls per step, i.e. O(d^2) work per step -- hours from a few thousand dimensions on.  Never started
+        # silently there: the caller gets the descriptor to use instead (TSU_LANGEVIN_HOST=1 runs it anyway).
+        d_ = int(np.atleast_1d(x_init).size)
+        if d_ > _PROBE_FULL_MAX and os.environ.get("TSU_LANGEVIN_HOST", "0") != "1":
+            steps = (self.config.n_burnin + self.config.n_steps) * n_samples
+            raise SamplingError(
+                f"energy_fn is not a uniform separable quadratic and dim = {d_}: the reference's finite-difference Langevin loop "
+                f"would make {2 * d_ * steps:.3g} energy calls of O(dim) work on the host.  Pass a tsu.core.QuadraticEnergy(k, mu) "
+                f"descriptor (k, mu scalars or arrays of length dim) to run on the GPU, or set TSU_LANGEVIN_HOST=1 to run the "
+                f"host loop anyway.")
         cfg = self.config
         x_init = np.asarray(x_init, dtype=float)
         x = np.atleast_1d(x_init).copy()
