@@ -32,13 +32,16 @@
                                 // OWN_RING superblocks, checked by the host)
 #define OWN_TAG_SPAN 16384u     // generation g of superblock number q carries tag q * SPAN + g + 1 (0 = never written)
 #define OWN_MAX_R 8
+#define OWN_NGEN 16            // generation buffers (a ring by generation number): the deciders of a superblock move in lockstep and need two;
+                                // the FOLLOWERS (below) read the same buffers without being waited for and may lag up to OWN_NGEN - 2 generations
+                                // (they notice an overwritten buffer by its tag and fail the call -- the caller's other paths redo it)
 
 struct OwnParams {
     const void* JT;
     const double* bias;
     int8_t* state;               // [R][n] values, committed in place superblock by superblock
     const double* uniforms;      // [R][n_sweeps][n] replayed uniforms (indexed by position) or nullptr
-    unsigned long long* gen;     // [2][R][G][2] granules of the running generation (two buffers by generation parity)
+    unsigned long long* gen;     // [OWN_NGEN][R][G][2] granules of the running generations (ring by generation number)
     unsigned long long* fin;     // [OWN_RING][R][G][2] granules of the final values of a superblock (tag = superblock number + 1)
     unsigned* bar;               // error words (BAR_ERR page layout of dense_dev.h)
     const int64_t* order;        // [n_sweeps][n] visiting orders, or nullptr (natural order)
@@ -105,60 +108,81 @@ struct OwnQuad<double> {
     __device__ __forceinline__ double get(int m) const { return m == 0 ? a.x : m == 1 ? a.y : m == 2 ? b.x : b.y; }
 };
 
+// entries [k0, k1) of the list into acc (MASKED: per-lane masks as MODE says; else every entry to every row).  Bundles of ES consecutive
+// entries, wave wv takes bundles wv, wv + 16, ..., U of them in flight per lane.  (Tried and dropped: two groups of four bundles in
+// flight alternately with unconditional loads -- the dummy loads of short lists and the longer prologue cost more than the overlap
+// gained: 0.29 -> 0.36 ms per sweep at n = 16384.)
+template <typename TJ, int M, int R, int MODE, bool MASKED>
+static __device__ __forceinline__ void own_axpy_range(const TJ* __restrict__ JT, int n, const uint32_t* lst, int k0, int k1, int col0, int myrow,
+                                                      const unsigned short* pos, const int* mypos, double (*acc)[4], int lane, int wv) {
+    constexpr int QL = 16 * M, ES = 4 / M;
+    constexpr int U = 4;  // bundles in flight per lane (tools/microbench_axpy: 64 workgroups x 1700 entries take 7.0 us with 4, 10.4 with 8, 8.3 with 2)
+    const int t = lane / QL;                 // my entry slot
+    const int nb = (k1 - k0 + ES - 1) / ES;  // bundles
+    if (wv >= nb) return;
+    auto consume = [&](const OwnQuad<TJ>& xq, uint32_t ev) {
+        const int j = (int)(ev & 0xFFFFu);
+        const uint32_t code = ev >> 16;
+        double v[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) v[m] = xq.get(m);
+        if (MODE == 2) {
+            const double sg = (code & 1u) ? ((code & 2u) ? -1.0 : 1.0) : 0.0;
+            const int pj = pos[j];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                acc[1][m] += sg * v[m];
+                acc[0][m] += pj < mypos[m] ? sg * v[m] : 0.0;
+            }
+        } else {
+            if (MASKED) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) v[m] = j < myrow + m ? v[m] : 0.0;
+            }
+#pragma unroll
+            for (int rho = 0; rho < R; ++rho) {
+                const uint32_t c = (code >> (2 * rho)) & 3u;
+                const double sg = (c & 1u) ? ((c & 2u) ? -1.0 : 1.0) : 0.0;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[rho][m] += sg * v[m];
+            }
+        }
+    };
+    for (int b = wv; b < nb; b += OWN_WAVES * U) {
+        OwnQuad<TJ> x[U];
+        uint32_t e[U];
+        // (the bundle tests are wave-uniform -- wv is scalar: a wave issues loads for its own bundles only, short lists cost one round trip)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + (b + OWN_WAVES * u) * ES + t;
+            e[u] = k < k1 ? lst[k] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (b + OWN_WAVES * u < nb) x[u].load(JT + (size_t)(e[u] & 0xFFFFu) * n + col0);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (b + OWN_WAVES * u < nb) consume(x[u], e[u]);
+    }
+}
+
+// nlo: (MODE 1) entries [0, nlo) belong to sites before the workgroup's first row (every row takes them: no masks), [nlo, nl) to
+// the workgroup's own sites (per-lane masks)
 template <typename TJ, int M, int R, int MODE, int NA>
-static __device__ __forceinline__ void own_axpy(const TJ* __restrict__ JT, int n, const uint32_t* lst, int nl, int col0, int myrow,
+static __device__ __forceinline__ void own_axpy(const TJ* __restrict__ JT, int n, const uint32_t* lst, int nlo, int nl, int col0, int myrow,
                                                 const unsigned short* pos, const int* mypos, double* red, int lane, int wv) {
-    constexpr int QL = 16 * M;   // quads (lanes) per entry slot
-    constexpr int ES = 4 / M;    // entry slots per wave-instruction
+    constexpr int QL = 16 * M, ES = 4 / M;
     constexpr int NS = MODE == 2 ? 2 : R;
-    constexpr int U = (sizeof(TJ) == 8 || R >= 4) ? 4 : 8;
-    const int t = lane / QL;     // my entry slot
     double acc[NS][4];
 #pragma unroll
     for (int a = 0; a < NS; ++a)
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc[a][m] = 0.0;
-    const int nb = (nl + ES - 1) / ES;  // bundles
-    for (int b = wv; b < nb; b += OWN_WAVES * U) {
-        OwnQuad<TJ> x[U];
-        uint32_t e[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int k = (b + OWN_WAVES * u) * ES + t;
-            e[u] = k < nl ? lst[k] : 0u;
-            x[u].load(JT + (size_t)(e[u] & 0xFFFFu) * n + col0);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t ev = e[u];
-            const int j = (int)(ev & 0xFFFFu);
-            const uint32_t code = ev >> 16;
-            double v[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) v[m] = x[u].get(m);
-            if (MODE == 2) {
-                const double sg = (code & 1u) ? ((code & 2u) ? -1.0 : 1.0) : 0.0;
-                const int pj = pos[j];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const double sv = sg * v[m];
-                    acc[1][m] += sv;
-                    acc[0][m] += pj < mypos[m] ? sv : 0.0;
-                }
-            } else {
-                if (MODE == 1) {
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) v[m] = j < myrow + m ? v[m] : 0.0;
-                }
-#pragma unroll
-                for (int rho = 0; rho < R; ++rho) {
-                    const uint32_t c = (code >> (2 * rho)) & 3u;
-                    const double sg = (c & 1u) ? ((c & 2u) ? -1.0 : 1.0) : 0.0;
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) acc[rho][m] += sg * v[m];
-                }
-            }
-        }
+    if (MODE == 1) {
+        own_axpy_range<TJ, M, R, 1, false>(JT, n, lst, 0, nlo, col0, myrow, pos, mypos, acc, lane, wv);
+        own_axpy_range<TJ, M, R, 1, true>(JT, n, lst, nlo, nl, col0, myrow, pos, mypos, acc, lane, wv);
+    } else {
+        own_axpy_range<TJ, M, R, MODE, MODE == 2>(JT, n, lst, 0, nl, col0, myrow, pos, mypos, acc, lane, wv);
     }
     // the entry slots of a quad: lanes q, q + QL, ... (fixed order: ((0 + 1) + (2 + 3)))
 #pragma unroll
@@ -186,8 +210,8 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
     constexpr int NA = ORD ? 2 : R;      // accumulator slots of the axpy pass
     constexpr int PW = M;                // the wave that polls and builds the lists (the first one that owns no rows)
     extern __shared__ unsigned long long own_lds[];
-    __shared__ int s_nl, s_nle, s_fail;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ int s_nl, s_nlo, s_nle, s_fail;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int w = (int)blockIdx.x, W = (int)gridDim.x, G = W * M;
     const int n = P.n;
     const TJ* __restrict__ JT = (const TJ*)P.JT;
@@ -215,7 +239,8 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
     if (threadIdx.x == 0) s_fail = 0;
 
     const bool timing = P.timeline && (int)blockIdx.x == W - 1 && threadIdx.x == 0;
-    unsigned long long tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    __shared__ unsigned long long tl[12];  // (in LDS: a per-thread array would occupy registers of every wave)
+    if (threadIdx.x < 12) tl[threadIdx.x] = 0ull;
     long long tl_last = wall_clock64();
 #define OWN_MARK(kind)                                    \
     if (timing) {                                         \
@@ -243,6 +268,7 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
             const unsigned long long* p = buf + (size_t)(g_lo + (okk ? k : 0)) * 2;
             unsigned long long lo[R], hi[R];
             const long long t0 = wall_clock64();
+            bool missed = false;
             for (unsigned spins = 0;; ++spins) {
                 bool all = true;
 #pragma unroll
@@ -250,6 +276,13 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                     lo[rho] = ld(p + (size_t)rho * G * 2);
                     hi[rho] = ld(p + (size_t)rho * G * 2 + 1);
                     all = all && (unsigned)(lo[rho] >> 32) == tag && (unsigned)(hi[rho] >> 32) == tag;
+                    // (a follower that fell a whole ring behind finds a LATER generation's tag: tags only grow in a buffer)
+                    if (okk && ((unsigned)(lo[rho] >> 32) > tag || (unsigned)(hi[rho] >> 32) > tag)) missed = true;
+                }
+                if (__ballot(missed) != 0ull) {
+                    st(&P.bar[BAR_ERR], 1u);
+                    s_fail = 1;
+                    break;
                 }
                 if (__ballot(okk && !all) == 0ull) break;
                 if (sleepy) __builtin_amdgcn_s_sleep(16);
@@ -272,7 +305,10 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
     // including this workgroup's own groups (natural order: later sites never enter a correction).
     auto build_list = [&](const unsigned long long* newp, int sn, unsigned long long* oldp, int so, int g_lo, int np, bool write_back) {
         int base = 0;
-        if (lane == 0) s_nle = 0;
+        if (lane == 0) {
+            s_nle = 0;
+            s_nlo = 0;
+        }
         for (int k0 = 0; k0 < np; k0 += 64) {
             const int k = k0 + lane;
             const bool okk = k < np;
@@ -296,6 +332,7 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
             off = base + off - pc;
             const int g = g_lo + k;
             const int sbase = 64 * g;
+            if (okk && g == w * M) s_nlo = off;
             while (un) {
                 const int b = __ffsll((long long)un) - 1;
                 un &= un - 1ull;
@@ -311,16 +348,18 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
         if (lane == 0) s_nl = base;
     };
 
-    // (natural order) the workgroups that decide the NEXT superblock need its predecessor's flips first: everybody else holds its own
-    // strip back until their first generation is out (a hint only -- bounded, nothing depends on it: 30 us at most)
+    // (natural order) the workgroups that decide the NEXT superblock have its predecessor's flips already (they followed its generations)
+    // and now run their first, long correction pass (every first guess that flips): everybody else holds its own strip back until
+    // their second generation is out (a hint only -- bounded, nothing depends on it: 30 us at most)
     auto yield_to_next = [&](unsigned seq_now, int sb_now, int sw_now) {
         const int nsb_ = (W + P.sbw - 1) / P.sbw;
         const int sbn = sb_now + 1 < nsb_ ? sb_now + 1 : 0;
-        if (nsb_ < 2 || w / P.sbw == sbn || (sbn == 0 && sw_now + 1 >= P.n_sweeps)) return;
+        const int sbnn = sbn + 1 < nsb_ ? sbn + 1 : 0;  // its followers are on a tight schedule too (they must keep up with the generations)
+        if (nsb_ < 2 || w / P.sbw == sbn || w / P.sbw == sbnn || (sbn == 0 && sw_now + 1 >= P.n_sweeps)) return;
         if (lane == 0) {
             const int gl = ((sbn + 1) * P.sbw * M < G ? (sbn + 1) * P.sbw * M : G) - 1;
-            const unsigned long long* p = P.gen + (size_t)gl * 2;  // generation parity 0, replica 0
-            const unsigned want = (seq_now + 1u) * OWN_TAG_SPAN + 1u;
+            const unsigned long long* p = P.gen + ((size_t)1 * R * G + gl) * 2;  // generation buffer 1, replica 0
+            const unsigned want = (seq_now + 1u) * OWN_TAG_SPAN + 2u;
             const long long t0 = wall_clock64();
             while ((unsigned)(ld(p) >> 32) < want && wall_clock64() - t0 < 3000) __builtin_amdgcn_s_sleep(32);
         }
@@ -378,7 +417,7 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                     if (wv == PW) build_list(vmask + g0, G, nullptr, 0, g0, np, false);
                     __syncthreads();
                     const int nl = s_nl;
-                    own_axpy<TJ, M, R, 0, NA>(JT, n, lst, nl, col0, myrow, pos, mypos, red, lane, wv);
+                    own_axpy<TJ, M, R, 0, NA>(JT, n, lst, 0, nl, col0, myrow, pos, mypos, red, lane, wv);
                     __syncthreads();
                     if (decider) {
 #pragma unroll
@@ -420,7 +459,7 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                 OWN_MARK(0);
                 while (true) {
                     const unsigned tag = seq * OWN_TAG_SPAN + gi + 1u;
-                    unsigned long long* gbuf = P.gen + (size_t)(gi & 1u) * R * G * 2;
+                    unsigned long long* gbuf = P.gen + (size_t)(gi % OWN_NGEN) * R * G * 2;
                     if (decider) {
 #pragma unroll
                         for (int rho = 0; rho < R; ++rho) {
@@ -441,14 +480,14 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                     __syncthreads();
                     if (s_fail) return;
                     const int nl = s_nl;
-                    OWN_MARK(1);
+                    OWN_MARK(gi == 0 ? 9 : 1);
                     if (timing) {
                         tl[4] += 1;
                         tl[5] += (unsigned long long)nl;
                     }
                     if (nl == 0) break;  // nobody's value changed: the fixed point
-                    if (ORD) own_axpy<TJ, M, R, 2, NA>(JT, n, lst, nl, col0, myrow, pos, mypos, red, lane, wv);
-                    else own_axpy<TJ, M, R, 1, NA>(JT, n, lst, s_nle, col0, myrow, pos, mypos, red, lane, wv);
+                    if (ORD) own_axpy<TJ, M, R, 2, NA>(JT, n, lst, 0, nl, col0, myrow, pos, mypos, red, lane, wv);
+                    else own_axpy<TJ, M, R, 1, NA>(JT, n, lst, s_nlo, s_nle, col0, myrow, pos, mypos, red, lane, wv);
                     __syncthreads();
                     if (decider) {
                         if (ORD) {
@@ -459,12 +498,12 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                             for (int rho = 0; rho < R; ++rho) dC[OWN_AT(rho)] += reduced(rho);
                         }
                     }
+                    OWN_MARK(gi == 0 ? 8 : 2);
                     ++gi;
                     if (gi + 2u >= OWN_TAG_SPAN) {  // cannot happen (the iteration is exact after as many generations as the superblock has positions)
                         if (threadIdx.x == 0) st(&P.bar[BAR_ERR + 2], 1u);
                         return;
                     }
-                    OWN_MARK(2);
                 }
                 __syncthreads();  // (every wave has read s_nl before the poller writes it again)
                 // converged: gm holds the final values.  Commit my site, publish the final masks for the workgroups that did not follow
@@ -501,7 +540,7 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                     }
                     __syncthreads();
                     const int nl = s_nl;
-                    own_axpy<TJ, M, R, 0, NA>(JT, n, lst, nl, col0, myrow, pos, mypos, red, lane, wv);
+                    own_axpy<TJ, M, R, 0, NA>(JT, n, lst, 0, nl, col0, myrow, pos, mypos, red, lane, wv);
                     __syncthreads();
                     if (decider) {
 #pragma unroll
@@ -511,31 +550,71 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                 }
                 OWN_MARK(3);
             } else {
-                // not my superblock: wait for its final values, apply the flips to my rows
-                OWN_MARK(0);
-                if (wv == PW) {
-                    poll(P.fin + (size_t)slot * R * G * 2, seq + 1u, g_lo, np, true);
-                    build_list(nm, NP, vmask + g_lo, G, g_lo, np, true);
-                    yield_to_next(seq, sb, sw);
-                }
-                __syncthreads();
-                if (s_fail) return;
-                OWN_MARK(6);
-                const int nl = s_nl;
-                own_axpy<TJ, M, R, 0, NA>(JT, n, lst, nl, col0, myrow, pos, mypos, red, lane, wv);
-                __syncthreads();
-                if (decider) {
+                const int nsb_n = nsb;
+                const bool follower = w / P.sbw == (sb + 1 < nsb_n ? sb + 1 : 0);
+                if (follower) {
+                    // my superblock is the NEXT one: follow this superblock's generations as its deciders do -- every generation's
+                    // toggles go to all my rows at once (unmasked), in generation order: when it converges my fields are complete and
+                    // my own first generation starts at once, instead of after a strip of ~1700 row segments.  Not waited for by
+                    // anybody: the generation buffers are a ring, a missed generation fails the call (never seen: a follower's pass
+                    // over a generation costs a third of a decider's).
+                    OWN_MARK(0);
+                    for (int q = (int)threadIdx.x; q < R * np; q += OWN_THREADS) {
+                        const int rho = q / np, k = q - rho * np;
+                        gm[rho * NP + k] = vmask[rho * G + g_lo + k];
+                    }
+                    __syncthreads();
+                    for (unsigned gi = 0;; ++gi) {
+                        if (wv == PW) {
+                            poll(P.gen + (size_t)(gi % OWN_NGEN) * R * G * 2, seq * OWN_TAG_SPAN + gi + 1u, g_lo, np, false);
+                            build_list(nm, NP, gm, NP, g_lo, np, true);
+                        }
+                        __syncthreads();
+                        if (s_fail) return;
+                        const int nl = s_nl;
+                        if (nl == 0) break;
+                        own_axpy<TJ, M, R, 0, NA>(JT, n, lst, 0, nl, col0, myrow, pos, mypos, red, lane, wv);
+                        __syncthreads();
+                        if (decider) {
 #pragma unroll
-                    for (int rho = 0; rho < R; ++rho) dF[OWN_AT(rho)] += reduced(rho);
+                            for (int rho = 0; rho < R; ++rho) dF[OWN_AT(rho)] += reduced(rho);
+                        }
+                        if (gi + 3u >= OWN_TAG_SPAN) return;  // (the deciders have failed the call)
+                    }
+                    __syncthreads();
+                    for (int q = (int)threadIdx.x; q < R * np; q += OWN_THREADS) {
+                        const int rho = q / np, k = q - rho * np;
+                        vmask[rho * G + g_lo + k] = gm[rho * NP + k];
+                    }
+                    __syncthreads();
+                    OWN_MARK(6);
+                } else {
+                    // not my superblock, nor the one before mine: wait for its final values, apply the flips to my rows
+                    OWN_MARK(0);
+                    if (wv == PW) {
+                        poll(P.fin + (size_t)slot * R * G * 2, seq + 1u, g_lo, np, true);
+                        build_list(nm, NP, vmask + g_lo, G, g_lo, np, true);
+                        yield_to_next(seq, sb, sw);
+                    }
+                    __syncthreads();
+                    if (s_fail) return;
+                    OWN_MARK(6);
+                    const int nl = s_nl;
+                    own_axpy<TJ, M, R, 0, NA>(JT, n, lst, 0, nl, col0, myrow, pos, mypos, red, lane, wv);
+                    __syncthreads();
+                    if (decider) {
+#pragma unroll
+                        for (int rho = 0; rho < R; ++rho) dF[OWN_AT(rho)] += reduced(rho);
+                    }
+                    __syncthreads();
+                    OWN_MARK(7);
                 }
-                __syncthreads();
-                OWN_MARK(7);
             }
         }
     }
     if (P.persist && site_ok) P.fields_all[site] = dF[OWN_AT(0)];
     if (timing)
-        for (int x = 0; x < 8; ++x) P.timeline[x] = tl[x];
+        for (int x = 0; x < 12; ++x) P.timeline[x] = tl[x];
 #undef OWN_MARK
 #undef OWN_AT
 }
@@ -604,7 +683,7 @@ int tsu_dense_own_run(tsu_dense* d, int R_real, const OwnRep* reps, int8_t* stat
         (void)hipGetLastError();
         return TSU_OK;
     }
-    const size_t gen_words = (size_t)2 * R * G * 2, fin_words = (size_t)OWN_RING * R * G * 2;
+    const size_t gen_words = (size_t)OWN_NGEN * R * G * 2, fin_words = (size_t)OWN_RING * R * G * 2;
     if (d->own_cap < gen_words + fin_words) {
         if (d->own_gran) (void)hipFree(d->own_gran);
         d->own_gran = nullptr;
@@ -644,8 +723,8 @@ int tsu_dense_own_run(tsu_dense* d, int R_real, const OwnRep* reps, int8_t* stat
     static const int verbose = own_env("TSU_K2_VERBOSE", 0);
     unsigned long long* d_tl = nullptr;
     if (verbose >= 2) {
-        TSU_HIP_TRY(ctx, hipMalloc(&d_tl, 8 * sizeof(unsigned long long)));
-        TSU_HIP_TRY(ctx, hipMemsetAsync(d_tl, 0, 8 * sizeof(unsigned long long), ctx->stream));
+        TSU_HIP_TRY(ctx, hipMalloc(&d_tl, 12 * sizeof(unsigned long long)));
+        TSU_HIP_TRY(ctx, hipMemsetAsync(d_tl, 0, 12 * sizeof(unsigned long long), ctx->stream));
     }
     P.timeline = d_tl;
     {
@@ -666,13 +745,13 @@ int tsu_dense_own_run(tsu_dense* d, int R_real, const OwnRep* reps, int8_t* stat
     TSU_HIP_TRY(ctx, hipMemcpyAsync(h + 1, d->co_bar + BAR_ERR, 3 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
     TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (d_tl) {
-        unsigned long long tl[8];
+        unsigned long long tl[12];
         (void)hipMemcpy(tl, d_tl, sizeof(tl), hipMemcpyDeviceToHost);
         (void)hipFree(d_tl);
         const double per = (double)n_sweeps * (ord ? nsb : 1);  // the timed workgroup is active once per sweep in natural order
-        fprintf(stderr, "[tsu] k2_own n=%d R=%d M=%d %s, superblocks of %d, %d sweeps; last workgroup, per active superblock: prologue %.1f us, polls %.1f us, "
-                        "axpy+decide %.1f us, commit+strip %.1f us, %.1f generations, %.0f toggles; per sweep as a bystander: wait %.1f us, strips %.1f us\n",
-                n, R, M, ord ? "caller's order" : "natural order", sbw * RW, n_sweeps, tl[0] / 100.0 / per, tl[1] / 100.0 / per, tl[2] / 100.0 / per,
+        fprintf(stderr, "[tsu] k2_own n=%d R=%d M=%d %s, superblocks of %d, %d sweeps; last workgroup, per active superblock: prologue %.1f us, first poll %.1f us, first axpy %.1f us, "
+                        "later polls %.1f us, later axpy+decide %.1f us, commit+strip %.1f us, %.1f generations, %.0f toggles; per sweep as a bystander: wait %.1f us, strips %.1f us\n",
+                n, R, M, ord ? "caller's order" : "natural order", sbw * RW, n_sweeps, tl[0] / 100.0 / per, tl[9] / 100.0 / per, tl[8] / 100.0 / per, tl[1] / 100.0 / per, tl[2] / 100.0 / per,
                 tl[3] / 100.0 / per, tl[4] / per, tl[5] / per, tl[6] / 100.0 / n_sweeps, tl[7] / 100.0 / n_sweeps);
     }
     if (h[1] || h[3]) {
