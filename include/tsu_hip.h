@@ -209,6 +209,9 @@ int tsu_dense_energy(tsu_dense* d, double* energy); /* -1/2 s^T J s - b^T s of t
 /* the same for n_states given states (states_host: n_states x n bytes of 0/1; the resident state is not touched): the energies of
  * the states an annealing schedule recorded (simulated_annealing, gibbs.py:384-391, evaluates compute_energy after every step) */
 int tsu_dense_energies(tsu_dense* d, const int8_t* states_host, int n_states, double* energies_host);
+/* launches of the one-launch kernels this system has made so far (counts[0]: owner-computes kernel k2_own, counts[1]: pipeline
+ * k2_pipe) -- lets a caller or a test see which path its sweeps took (no reference counterpart) */
+int tsu_dense_launch_counts(tsu_dense* d, uint64_t counts[2]);
 
 /* ------------------------------------------------------------------ sparse coupling graph, colour-parallel (K5)
  * Replaces GibbsSampler.gibbs_sweep / sample_boltzmann / compute_energy (tsu/gibbs.py:79-236) for models whose

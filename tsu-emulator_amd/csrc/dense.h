@@ -52,6 +52,7 @@ struct tsu_dense {
     unsigned long long* own_gran;
     size_t own_cap;     // 8-byte words allocated in own_gran
     int own_failed;     // k2_own ran and gave up half way: the caller restores the state, later calls skip it
+    uint64_t n_own, n_pipe;  // successful launches of k2_own / k2_pipe (tsu_dense_launch_counts)
 };
 
 // per-replica parameters of a k2_own launch

@@ -1310,6 +1310,13 @@ int tsu_dense_energy(tsu_dense* d, double* energy) {
     return TSU_OK;
 }
 
+int tsu_dense_launch_counts(tsu_dense* d, uint64_t counts[2]) {
+    if (!d || !counts) return TSU_E_INVALID;
+    counts[0] = d->n_own;
+    counts[1] = d->n_pipe;
+    return TSU_OK;
+}
+
 int tsu_dense_energies(tsu_dense* d, const int8_t* states_host, int n_states, double* energies_host) {
     TSU_ENTER(d ? d->ctx : nullptr);
     if (!d) return TSU_E_INVALID;

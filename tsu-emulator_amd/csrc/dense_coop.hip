@@ -948,6 +948,7 @@ static int pipe_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, uint3
         return TSU_OK;
     }
     *done = 1;
+    d->n_pipe += 1;
     d->since_refresh = (P.refresh_off + n_sweeps) % CO_REFRESH;
     d->fields_valid = P.persist;
     d->pipe_streak += 1;

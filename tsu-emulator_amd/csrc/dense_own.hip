@@ -112,7 +112,7 @@ struct OwnQuad<double> {
 // entries, wave wv takes bundles wv, wv + 16, ..., U of them in flight per lane.  (Tried and dropped: two groups of four bundles in
 // flight alternately with unconditional loads -- the dummy loads of short lists and the longer prologue cost more than the overlap
 // gained: 0.29 -> 0.36 ms per sweep at n = 16384.)
-template <typename TJ, int M, int R, int MODE, bool MASKED>
+template <typename TJ, int M, int R0, int RN, int MODE, bool MASKED>
 static __device__ __forceinline__ void own_axpy_range(const TJ* __restrict__ JT, int n, const uint32_t* lst, int k0, int k1, int col0, int myrow,
                                                       const unsigned short* pos, const int* mypos, double (*acc)[4], int lane, int wv) {
     constexpr int QL = 16 * M, ES = 4 / M;
@@ -140,8 +140,8 @@ static __device__ __forceinline__ void own_axpy_range(const TJ* __restrict__ JT,
                 for (int m = 0; m < 4; ++m) v[m] = j < myrow + m ? v[m] : 0.0;
             }
 #pragma unroll
-            for (int rho = 0; rho < R; ++rho) {
-                const uint32_t c = (code >> (2 * rho)) & 3u;
+            for (int rho = 0; rho < RN; ++rho) {
+                const uint32_t c = (code >> (2 * (R0 + rho))) & 3u;
                 const double sg = (c & 1u) ? ((c & 2u) ? -1.0 : 1.0) : 0.0;
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc[rho][m] += sg * v[m];
@@ -172,34 +172,90 @@ template <typename TJ, int M, int R, int MODE, int NA>
 static __device__ __forceinline__ void own_axpy(const TJ* __restrict__ JT, int n, const uint32_t* lst, int nlo, int nl, int col0, int myrow,
                                                 const unsigned short* pos, const int* mypos, double* red, int lane, int wv) {
     constexpr int QL = 16 * M, ES = 4 / M;
-    constexpr int NS = MODE == 2 ? 2 : R;
-    double acc[NS][4];
+    // replicas in groups of four per pass over the list (eight replicas x four rows of f64 accumulators do not fit the registers
+    // beside the loads in flight; the second pass finds the segments in the caches)
+    constexpr int RG = MODE == 2 ? 1 : (R > 4 ? 4 : R);
+    constexpr int NS = MODE == 2 ? 2 : RG;
 #pragma unroll
-    for (int a = 0; a < NS; ++a)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) acc[a][m] = 0.0;
-    if (MODE == 1) {
-        own_axpy_range<TJ, M, R, 1, false>(JT, n, lst, 0, nlo, col0, myrow, pos, mypos, acc, lane, wv);
-        own_axpy_range<TJ, M, R, 1, true>(JT, n, lst, nlo, nl, col0, myrow, pos, mypos, acc, lane, wv);
-    } else {
-        own_axpy_range<TJ, M, R, MODE, MODE == 2>(JT, n, lst, 0, nl, col0, myrow, pos, mypos, acc, lane, wv);
-    }
-    // the entry slots of a quad: lanes q, q + QL, ... (fixed order: ((0 + 1) + (2 + 3)))
-#pragma unroll
-    for (int a = 0; a < NS; ++a)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            double z = acc[a][m];
-            if (ES >= 2) z += __shfl_xor(z, QL, 64);
-            if (ES >= 4) z += __shfl_xor(z, 2 * QL, 64);
-            acc[a][m] = z;
-        }
-    if (lane < QL) {
+    for (int r0 = 0; r0 < (MODE == 2 ? 1 : R); r0 += RG) {
+        double acc[NS][4];
 #pragma unroll
         for (int a = 0; a < NS; ++a)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) red[(wv * NA + a) * (64 * M) + 4 * lane + m] = acc[a][m];
+            for (int m = 0; m < 4; ++m) acc[a][m] = 0.0;
+        if (MODE == 1) {
+            if (r0 == 0) {
+                own_axpy_range<TJ, M, 0, RG, 1, false>(JT, n, lst, 0, nlo, col0, myrow, pos, mypos, acc, lane, wv);
+                own_axpy_range<TJ, M, 0, RG, 1, true>(JT, n, lst, nlo, nl, col0, myrow, pos, mypos, acc, lane, wv);
+            } else {
+                own_axpy_range<TJ, M, (R > 4 ? 4 : 0), RG, 1, false>(JT, n, lst, 0, nlo, col0, myrow, pos, mypos, acc, lane, wv);
+                own_axpy_range<TJ, M, (R > 4 ? 4 : 0), RG, 1, true>(JT, n, lst, nlo, nl, col0, myrow, pos, mypos, acc, lane, wv);
+            }
+        } else if (MODE == 2) {
+            own_axpy_range<TJ, M, 0, 1, 2, true>(JT, n, lst, 0, nl, col0, myrow, pos, mypos, acc, lane, wv);
+        } else {
+            if (r0 == 0) own_axpy_range<TJ, M, 0, RG, 0, false>(JT, n, lst, 0, nl, col0, myrow, pos, mypos, acc, lane, wv);
+            else own_axpy_range<TJ, M, (R > 4 ? 4 : 0), RG, 0, false>(JT, n, lst, 0, nl, col0, myrow, pos, mypos, acc, lane, wv);
+        }
+        // the entry slots of a quad: lanes q, q + QL, ... (fixed order: ((0 + 1) + (2 + 3)))
+#pragma unroll
+        for (int a = 0; a < NS; ++a)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                double z = acc[a][m];
+                if (ES >= 2) z += __shfl_xor(z, QL, 64);
+                if (ES >= 4) z += __shfl_xor(z, 2 * QL, 64);
+                acc[a][m] = z;
+            }
+        if (lane < QL) {
+#pragma unroll
+            for (int a = 0; a < NS; ++a)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) red[(wv * NA + r0 + a) * (64 * M) + 4 * lane + m] = acc[a][m];
+        }
     }
+}
+
+// The axpy pass for SEVERAL replicas (M = 1): one list entry per wave-instruction, lane = row (one dword per lane).  The entry and its
+// per-replica codes are wave-uniform (scalar): the sign of a replica is a scalar multiplier (one multiply-add per replica and
+// entry, nothing per lane to decode), and a lane holds one f64 accumulator per replica instead of four.  (The quad layout, which loads four entries per instruction, pays 8 multiply-adds per element
+// whatever the codes are and needed two passes over the list for its 32 accumulators: 1.38 ms per all-replica sweep at n = 16384.)
+template <typename TJ, int R, bool MASKED, int NA>
+static __device__ __forceinline__ void own_axpy_rep(const TJ* __restrict__ JT, int n, const uint32_t* lst, int nl, int col, int myrow, double* red,
+                                                    int lane, int wv) {
+    constexpr int U = 8;
+    double acc[R];
+#pragma unroll
+    for (int rho = 0; rho < R; ++rho) acc[rho] = 0.0;
+    for (int k = wv; k < nl; k += OWN_WAVES * U) {
+        TJ x[U];
+        uint32_t e[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) e[u] = k + OWN_WAVES * u < nl ? lst[k + OWN_WAVES * u] : 0u;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (k + OWN_WAVES * u < nl) {
+                const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[u]) & 0xFFFFu;
+                x[u] = JT[(size_t)j * n + col];
+            }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (k + OWN_WAVES * u < nl) {
+                const uint32_t ev = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[u]);
+                const int j = (int)(ev & 0xFFFFu);
+                double v = (double)x[u];
+                if (MASKED) v = j < myrow ? v : 0.0;
+#pragma unroll
+                for (int rho = 0; rho < R; ++rho) {
+                    // (a scalar multiplier: written as a branch the compiler turns the skip into five selects per replica)
+                    const uint32_t c = (ev >> (16 + 2 * rho)) & 3u;
+                    const double sg = c ? ((c & 2u) ? -1.0 : 1.0) : 0.0;
+                    acc[rho] = fma(sg, v, acc[rho]);
+                }
+            }
+    }
+#pragma unroll
+    for (int rho = 0; rho < R; ++rho) red[(wv * NA + rho) * 64 + lane] = acc[rho];
 }
 
 // ------------------------------------------------------------------------------------------------------------------ the kernel
@@ -237,6 +293,18 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
     const bool site_ok = decider && site < n;
     const int mygroup = w * M + (decider ? wv : 0);
     if (threadIdx.x == 0) s_fail = 0;
+    // the axpy pass in the layout that suits the replica count (see own_axpy / own_axpy_rep)
+#define OWN_AXPY_ALL(nl_)                                                                                        \
+    do {                                                                                                         \
+        if (R > 1) own_axpy_rep<TJ, R, false, NA>(JT, n, lst, (nl_), rcol, r0 + lane, red, lane, wv);            \
+        else own_axpy<TJ, M, R, 0, NA>(JT, n, lst, 0, (nl_), col0, myrow, pos, mypos, red, lane, wv);            \
+    } while (0)
+#define OWN_AXPY_GEN(nlo_, nle_)                                                                                 \
+    do {                                                                                                         \
+        if (R > 1) own_axpy_rep<TJ, R, true, NA>(JT, n, lst, (nle_), rcol, r0 + lane, red, lane, wv);            \
+        else own_axpy<TJ, M, R, 1, NA>(JT, n, lst, (nlo_), (nle_), col0, myrow, pos, mypos, red, lane, wv);      \
+    } while (0)
+    const int rcol = r0 + lane < n ? r0 + lane : n - 1;  // (replica layout: lane = row)
 
     const bool timing = P.timeline && (int)blockIdx.x == W - 1 && threadIdx.x == 0;
     __shared__ unsigned long long tl[12];  // (in LDS: a per-thread array would occupy registers of every wave)
@@ -262,29 +330,35 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
     // ---- the poller wave's tools -------------------------------------------------------------------------------------------
     // poll the granules of groups [g_lo, g_lo + np) of every replica in `buf` until all carry `tag`; the masks go to nm
     auto poll = [&](const unsigned long long* buf, unsigned tag, int g_lo, int np, bool sleepy) {
-        for (int k0 = 0; k0 < np; k0 += 64) {
-            const int k = k0 + lane;
-            const bool okk = k < np;
-            const unsigned long long* p = buf + (size_t)(g_lo + (okk ? k : 0)) * 2;
-            unsigned long long lo[R], hi[R];
+        constexpr int PC = R == 1 ? 4 : 1;  // chunks of 64 groups polled together (one round trip for 256 groups, not four)
+        for (int k0 = 0; k0 < np; k0 += 64 * PC) {
+            unsigned long long lo[PC][R], hi[PC][R];
             const long long t0 = wall_clock64();
             bool missed = false;
             for (unsigned spins = 0;; ++spins) {
                 bool all = true;
 #pragma unroll
-                for (int rho = 0; rho < R; ++rho) {
-                    lo[rho] = ld(p + (size_t)rho * G * 2);
-                    hi[rho] = ld(p + (size_t)rho * G * 2 + 1);
-                    all = all && (unsigned)(lo[rho] >> 32) == tag && (unsigned)(hi[rho] >> 32) == tag;
-                    // (a follower that fell a whole ring behind finds a LATER generation's tag: tags only grow in a buffer)
-                    if (okk && ((unsigned)(lo[rho] >> 32) > tag || (unsigned)(hi[rho] >> 32) > tag)) missed = true;
+                for (int c = 0; c < PC; ++c) {
+                    if (k0 + 64 * c >= np) break;  // (wave-uniform)
+                    const int k = k0 + 64 * c + lane;
+                    const bool okk = k < np;
+                    const unsigned long long* p = buf + (size_t)(g_lo + (okk ? k : 0)) * 2;
+#pragma unroll
+                    for (int rho = 0; rho < R; ++rho) {
+                        lo[c][rho] = ld(p + (size_t)rho * G * 2);
+                        hi[c][rho] = ld(p + (size_t)rho * G * 2 + 1);
+                        const unsigned tl_ = (unsigned)(lo[c][rho] >> 32), th_ = (unsigned)(hi[c][rho] >> 32);
+                        all = all && (!okk || (tl_ == tag && th_ == tag));
+                        // (a follower that fell a whole ring behind finds a LATER generation's tag: tags only grow in a buffer)
+                        if (okk && (tl_ > tag || th_ > tag)) missed = true;
+                    }
                 }
                 if (__ballot(missed) != 0ull) {
                     st(&P.bar[BAR_ERR], 1u);
                     s_fail = 1;
                     break;
                 }
-                if (__ballot(okk && !all) == 0ull) break;
+                if (__ballot(!all) == 0ull) break;
                 if (sleepy) __builtin_amdgcn_s_sleep(16);
                 if ((spins & 63u) == 63u) {
                     if (ld(&P.bar[BAR_ERR]) || wall_clock64() - t0 > CO_TIMEOUT) {
@@ -294,9 +368,13 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                     }
                 }
             }
-            if (okk) {
 #pragma unroll
-                for (int rho = 0; rho < R; ++rho) nm[rho * NP + k] = (lo[rho] & 0xFFFFFFFFull) | (hi[rho] << 32);
+            for (int c = 0; c < PC; ++c) {
+                const int k = k0 + 64 * c + lane;
+                if (k < np) {
+#pragma unroll
+                    for (int rho = 0; rho < R; ++rho) nm[rho * NP + k] = (lo[c][rho] & 0xFFFFFFFFull) | (hi[c][rho] << 32);
+                }
             }
         }
     };
@@ -417,7 +495,7 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                     if (wv == PW) build_list(vmask + g0, G, nullptr, 0, g0, np, false);
                     __syncthreads();
                     const int nl = s_nl;
-                    own_axpy<TJ, M, R, 0, NA>(JT, n, lst, 0, nl, col0, myrow, pos, mypos, red, lane, wv);
+                    OWN_AXPY_ALL(nl);
                     __syncthreads();
                     if (decider) {
 #pragma unroll
@@ -435,16 +513,14 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
             const unsigned slot = seq % OWN_RING;
             if (active) {
                 const bool mine = site_ok && (!ORD || (dpos >= p0 && dpos < p1));  // my site is decided in this superblock
-                double Tw[R], invT[R];
-                const double* uni[R];
-                uint32_t tt[R];
+                // (per-replica parameters are read where they are used: eight replicas' worth of them hoisted here cost 200 scalar spills)
+#define OWN_UNI(rho) (P.uniforms ? P.uniforms + ((size_t)(rho) * P.n_sweeps + sw) * n : nullptr)
+#define OWN_TW(rho) (P.temps ? P.temps[sw] : P.rep[rho].T)
 #pragma unroll
                 for (int rho = 0; rho < R; ++rho) {
-                    Tw[rho] = P.temps ? P.temps[sw] : P.rep[rho].T;
-                    invT[rho] = 1.0 / Tw[rho];
-                    uni[rho] = P.uniforms ? P.uniforms + ((size_t)rho * P.n_sweeps + sw) * n : nullptr;
-                    tt[rho] = P.rep[rho].sweep0 + (uint32_t)sw;
-                    if (mine) dL[OWN_AT(rho)] = own_logit((uint32_t)site, (uint32_t)dpos, uni[rho], tt[rho], P.rep[rho].tag, P.rep[rho].k0, P.rep[rho].k1);
+                    if (mine)
+                        dL[OWN_AT(rho)] = own_logit((uint32_t)site, (uint32_t)dpos, OWN_UNI(rho), P.rep[rho].sweep0 + (uint32_t)sw, P.rep[rho].tag, P.rep[rho].k0,
+                                                    P.rep[rho].k1);
                     if (decider) dC[OWN_AT(rho)] = 0.0;
                 }
                 if (decider) dA[wv * 64 + lane] = 0.0;
@@ -464,9 +540,11 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
 #pragma unroll
                         for (int rho = 0; rho < R; ++rho) {
                             int v = (vcur >> rho) & 1;
-                            if (mine)
-                                v = own_decide(dF[OWN_AT(rho)] + dC[OWN_AT(rho)], dL[OWN_AT(rho)], Tw[rho], invT[rho], (uint32_t)site, (uint32_t)dpos, uni[rho], tt[rho], P.rep[rho].tag,
-                                               P.rep[rho].k0, P.rep[rho].k1);
+                            if (mine) {
+                                const double Tw = OWN_TW(rho);
+                                v = own_decide(dF[OWN_AT(rho)] + dC[OWN_AT(rho)], dL[OWN_AT(rho)], Tw, 1.0 / Tw, (uint32_t)site, (uint32_t)dpos, OWN_UNI(rho),
+                                               P.rep[rho].sweep0 + (uint32_t)sw, P.rep[rho].tag, P.rep[rho].k0, P.rep[rho].k1);
+                            }
                             vnew = (vnew & ~(1 << rho)) | (v << rho);
                             const unsigned long long mk = __ballot(v != 0);
                             if (lane < 2)
@@ -487,7 +565,7 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                     }
                     if (nl == 0) break;  // nobody's value changed: the fixed point
                     if (ORD) own_axpy<TJ, M, R, 2, NA>(JT, n, lst, 0, nl, col0, myrow, pos, mypos, red, lane, wv);
-                    else own_axpy<TJ, M, R, 1, NA>(JT, n, lst, s_nlo, s_nle, col0, myrow, pos, mypos, red, lane, wv);
+                    else OWN_AXPY_GEN(s_nlo, s_nle);
                     __syncthreads();
                     if (decider) {
                         if (ORD) {
@@ -540,7 +618,7 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                     }
                     __syncthreads();
                     const int nl = s_nl;
-                    own_axpy<TJ, M, R, 0, NA>(JT, n, lst, 0, nl, col0, myrow, pos, mypos, red, lane, wv);
+                    OWN_AXPY_ALL(nl);
                     __syncthreads();
                     if (decider) {
 #pragma unroll
@@ -573,7 +651,7 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                         if (s_fail) return;
                         const int nl = s_nl;
                         if (nl == 0) break;
-                        own_axpy<TJ, M, R, 0, NA>(JT, n, lst, 0, nl, col0, myrow, pos, mypos, red, lane, wv);
+                        OWN_AXPY_ALL(nl);
                         __syncthreads();
                         if (decider) {
 #pragma unroll
@@ -600,7 +678,7 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                     if (s_fail) return;
                     OWN_MARK(6);
                     const int nl = s_nl;
-                    own_axpy<TJ, M, R, 0, NA>(JT, n, lst, 0, nl, col0, myrow, pos, mypos, red, lane, wv);
+                    OWN_AXPY_ALL(nl);
                     __syncthreads();
                     if (decider) {
 #pragma unroll
@@ -617,6 +695,10 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
         for (int x = 0; x < 12; ++x) P.timeline[x] = tl[x];
 #undef OWN_MARK
 #undef OWN_AT
+#undef OWN_AXPY_ALL
+#undef OWN_UNI
+#undef OWN_TW
+#undef OWN_AXPY_GEN
 }
 
 // ---------------------------------------------------------------------------------------------------------------------- host side
@@ -646,13 +728,13 @@ int tsu_dense_own_run(tsu_dense* d, int R_real, const OwnRep* reps, int8_t* stat
     *done = 0;
     static const int use_own = own_env("TSU_K2_OWN", 1);
     static const int own_min = own_env("TSU_K2_OWN_MIN", 2048);
-    static const int sb_env = own_env("TSU_K2_OWN_SB", 0);
+    const int sb_env = own_env("TSU_K2_OWN_SB", 0), m_env = own_env("TSU_K2_OWN_M", 0);  // (read per call: tests vary them)
     if (!use_own || d->own_failed || n < own_min || n > 65536 || n_sweeps <= 0) return TSU_OK;
     const bool ord = order_dev != nullptr;
     if (R_real < 1 || R_real > OWN_MAX_R || (ord && R_real != 1)) return TSU_OK;
     const int R = R_real == 1 ? 1 : R_real == 2 ? 2 : R_real <= 4 ? 4 : 8;
     int M = 0;
-    for (int m = 1; m <= 4; m *= 2)
+    for (int m = (m_env == 2 || m_env == 4) ? m_env : 1; m <= 4; m *= 2)
         if ((n + 64 * m - 1) / (64 * m) <= ctx->cus) {
             M = m;
             break;
@@ -760,6 +842,7 @@ int tsu_dense_own_run(tsu_dense* d, int R_real, const OwnRep* reps, int8_t* stat
         return TSU_OK;
     }
     *done = 1;
+    d->n_own += 1;
     if (R_real == 1 && allow_persist) {
         d->since_refresh = (P.refresh_off + n_sweeps) % CO_REFRESH;
         d->fields_valid = P.persist;

@@ -90,6 +90,7 @@ SIGNATURES = {
     "tsu_dense_sweep_replicas": (C.c_int, [_vp, C.c_int, _f64p, C.c_int, _i8p, _u64p, _u32p, _u32p, _f64p]),
     "tsu_dense_energy": (C.c_int, [_vp, _f64p]),
     "tsu_dense_energies": (C.c_int, [_vp, _i8p, C.c_int, _f64p]),
+    "tsu_dense_launch_counts": (C.c_int, [_vp, _u64p]),
     "tsu_sparse_create": (C.c_int, [_vp, C.c_int, _i64p, _i32p, _f64p, _f64p, C.c_int, _i32p, _i32p, C.POINTER(_vp)]),
     "tsu_sparse_destroy": (C.c_int, [_vp]),
     "tsu_sparse_set_state": (C.c_int, [_vp, _i8p]),
@@ -444,6 +445,12 @@ class DenseSystem:
         e = C.c_double(0)
         self.ctx.check(self.lib.tsu_dense_energy(self.h, C.byref(e)))
         return e.value
+
+    def launch_counts(self):
+        """(launches of the owner-computes kernel k2_own, launches of the pipeline k2_pipe) made by this system so far."""
+        c = (C.c_uint64 * 2)()
+        self.ctx.check(self.lib.tsu_dense_launch_counts(self.h, c))
+        return int(c[0]), int(c[1])
 
     def energies(self, states):
         """Energies of the given states ((k, n) of 0/1), evaluated on the device in one call; the resident state stays as it is."""
