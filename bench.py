@@ -129,7 +129,7 @@ def issue_roofline(entry, updates_per_launch, launch_seconds, what="spin update"
             "note": "SQ_INSTS_VALU and GRBM_GUI_ACTIVE from profiles/counters.json (rocprofv3 --pmc passes), launch time from this run"}
 
 
-def time_lattice(hip, ctx, L, k, sweeps, reps=3, cols=None):
+def time_lattice(hip, ctx, L, k, sweeps, reps=3, cols=None, counters=None, ckey=None, sweeps_per_launch=None):
     rows, L = L, (cols or L)
     lat = hip.Lattice(rows, L, True, ctx=ctx)
     lat.randomize(42)
@@ -145,8 +145,18 @@ def time_lattice(hip, ctx, L, k, sweeps, reps=3, cols=None):
     s, b = lat.observables()
     lat.close()
     ups = rows * L * sweeps / (best * 1e-3)
-    return {"spin_updates_per_s": ups, "us_per_sweep": best * 1e3 / sweeps, "algorithmic_GBps": 2 * ups / 1e9,
-            "frac_of_8TBps": 2 * ups / 1e9 / HBM_PEAK_GBS, "M": s / (rows * L), "E_per_site": -b / (rows * L)}
+    out = {"spin_updates_per_s": ups, "us_per_sweep": best * 1e3 / sweeps, "algorithmic_GBps": 2 * ups / 1e9,
+           "frac_of_8TBps": 2 * ups / 1e9 / HBM_PEAK_GBS, "M": s / (rows * L), "E_per_site": -b / (rows * L)}
+    entry = (counters or {}).get(ckey) if ckey else None
+    if entry:
+        # the PMC figures are per launch of `sweeps_per_launch` sweeps (a tile-resident launch runs the whole call)
+        spl = sweeps_per_launch or sweeps
+        launch_s = best * 1e-3 * spl / sweeps
+        out["counters_key"] = ckey
+        out["traffic_bytes_per_launch"] = entry.get("hbm_bytes")
+        out["algorithmic_bytes_per_launch"] = 2.0 * rows * L * spl
+        out["issue_roofline"] = issue_roofline(entry, float(rows) * L * spl, launch_s)
+    return out
 
 
 def time_langevin(hip, ctx, counters):
@@ -195,31 +205,108 @@ def time_langevin(hip, ctx, counters):
 
 
 def time_dense(hip, ctx, counters, n=16384):
-    """BASELINE configs[2]: dense Gibbs, N=16384 fp32 couplings (1 GiB of J), natural visiting order (k2_pipe)."""
+    """BASELINE configs[2]: dense Gibbs, N=16384 fp32 couplings (1 GiB of J): natural visiting order (k2_own), a caller's order
+    (update_order="random": one permutation per sweep) and eight replicas on one J (tempering ladder / independent chains)."""
     rng = np.random.default_rng(42)
     G = rng.standard_normal((n, n)).astype(np.float32)
     J = ((G + G.T) / 2 / np.sqrt(n)).astype(np.float32)
     np.fill_diagonal(J, 0.0)
+    del G
     d = hip.DenseSystem(J, None, hip.DTYPE_F32, ctx=ctx)
     d.set_state(rng.integers(0, 2, size=n).astype(np.int8))
-    # a loop of calls in steady state: from the second consecutive call on the pipeline hands the fields from call to call, so
+    # a loop of calls in steady state: from the second consecutive call on the kernel hands the fields from call to call, so
     # the timed call neither rebuilds them from scratch nor is the first to leave them behind
     d.sweep(1.0, 2, seed=1, sweep0=0)
     d.sweep(1.0, 2, seed=1, sweep0=2)
     ctx.synchronize()
     ctx.timer_begin()
-    d.sweep(1.0, 16, seed=1, sweep0=4)  # one call = one launch: the fields are handed from sweep to sweep inside it
+    d.sweep(1.0, 16, seed=1, sweep0=4)  # one call = one launch: the fields stay with their rows' owners from sweep to sweep
     ms_call = ctx.timer_end()
     ms = ms_call / 16
-    d.close()
+    own, pipe = d.launch_counts()
     gbs = n * n * 4 / (ms * 1e-3) / 1e9
-    e = counters.get("k2_pipe_N16384_f32", {})
-    return {"N": n, "dtype": "f32", "ms_per_sweep": ms, "spin_updates_per_s": n / (ms * 1e-3), "J_stream_GBps": gbs,
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "traffic": e.get("hbm_bytes"),
-                         "note": "algorithmic N^2 x 4 B per sweep (J streamed once); the launch also reads the triangles of the first-guess "
-                                 "pass (4 x 33 MB per sweep); traffic = PMC bytes of a lone launch of 8 sweeps incl. its one full field pass "
-                                 "(profiles/r02_pmc_k2_pipe_N16384_f32.txt)"}}
+    e = counters.get("k2_own_N16384_f32", {})
+    out = {"N": n, "dtype": "f32", "ms_per_sweep": ms, "spin_updates_per_s": n / (ms * 1e-3), "J_stream_GBps": gbs,
+           "kernel": "k2_own" if own else "k2_pipe", "launches": {"k2_own": own, "k2_pipe": pipe},
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                        "traffic": e.get("hbm_bytes"),
+                        "note": "algorithmic N^2 x 4 B per sweep (J streamed once) / time per sweep; k2_own reads only the rows of J^T of "
+                                "the sites whose value changes (~41 % flip per sweep at T = 1, plus the toggles of the generations), so "
+                                "the PMC traffic per sweep is BELOW the algorithmic bytes (profiles/r03_pmc_k2_own_N16384_f32.txt)"}}
+    # update_order="random": the caller's permutation per sweep (uploaded with the call; validated on the host)
+    k = 8
+    order = np.array([rng.permutation(n) for _ in range(k)])
+    d.sweep(1.0, 2, seed=2, sweep0=0, order=order[:2])
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    d.sweep(1.0, k, seed=2, sweep0=2, order=order)
+    ctx.synchronize()
+    ms_r = (time.perf_counter() - t0) * 1e3 / k
+    out["random_order"] = {"ms_per_sweep": ms_r, "vs_natural": ms_r / ms, "roofline_frac": n * n * 4 / (ms_r * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "note": "wall clock of the call incl. the host-side permutation check and the upload of the orders (8 B per site and sweep)"}
+    # eight replicas on ONE stream of J (tsu_dense_sweep_replicas: parallel_tempering / sample_chains above the one-workgroup kernels)
+    R = 8
+    sts = np.array([np.random.default_rng(100 + r).integers(0, 2, size=n) for r in range(R)], dtype=np.int8)
+    sts = d.sweep_replicas(sts, [1.0] * R, 2, list(range(R)), [0] * R)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    d.sweep_replicas(sts, [1.0] * R, 8, list(range(R)), [2] * R)
+    ms_8 = (time.perf_counter() - t0) * 1e3 / 8
+    out["eight_replicas"] = {"ms_per_all_replica_sweep": ms_8, "vs_single_chain_sweep": ms_8 / ms, "replica_sweeps_per_s": R / (ms_8 * 1e-3),
+                             "note": "8 states advanced together by one launch; wall clock incl. the states' PCIe round trip (128 KiB each way)"}
+    d.close()
+    return out
+
+
+def time_python_surface(hip, ctx):
+    """The reference idioms through the Python surface, UNBOUND (no GibbsSampler.bind): what a caller who switches libraries sees.
+    ``state = s.gibbs_sweep(state, J)`` + ``s.compute_energy(state, J)`` per step with J writeable (every byte hashed per call, the
+    price of seeing in-place edits as the reference does) and with J frozen (``J.setflags(write=False)``: no hash, same API)."""
+    from tsu.core import QuadraticEnergy, ThermalSamplingUnit, TSUConfig
+    from tsu.gibbs import GibbsConfig, GibbsSampler
+    from tsu.models.ising import IsingModel2D
+    out = {}
+    for n in (4096, 16384):
+        rng = np.random.default_rng(n)
+        G = rng.standard_normal((n, n)).astype(np.float32)
+        J = ((G + G.T) / 2 / np.sqrt(n)).astype(np.float32)
+        np.fill_diagonal(J, 0.0)
+        del G
+        s = GibbsSampler(GibbsConfig(temperature=1.0), seed=5, coupling_dtype="float32")
+        state = rng.integers(0, 2, size=n)
+        row = {}
+        for label, steps in (("writeable_J_hashed_every_call", 3), ("frozen_J", 20)):
+            if label == "frozen_J":
+                J.setflags(write=False)
+            state = s.gibbs_sweep(state, J)
+            e = s.compute_energy(state, J)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                state = s.gibbs_sweep(state, J)
+                e = s.compute_energy(state, J)
+            row[label] = {"ms_per_step_sweep_plus_energy": (time.perf_counter() - t0) * 1e3 / steps}
+        row["energy"] = float(e)
+        s.invalidate()
+        out[f"gibbs_sweep_and_compute_energy_N{n}_f32"] = row
+    m = IsingModel2D(4096, temperature=T_C, seed=3)
+    m.gibbs_update(8)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        m.gibbs_update(8)
+    mag = m.magnetization()
+    dt = time.perf_counter() - t0
+    out["IsingModel2D_4096_gibbs_update_8_sweeps"] = {"ms_per_call": dt * 1e3 / 20, "spin_updates_per_s": 4096 * 4096 * 8 * 20 / dt, "M": float(mag)}
+    t = ThermalSamplingUnit(TSUConfig(temperature=1.0, dt=0.01, n_burnin=100, n_steps=400), seed=3)
+    t0 = time.perf_counter()
+    x = t.sample_boltzmann(QuadraticEnergy(2.0), n_samples=1, dim=2 ** 20)
+    dt = time.perf_counter() - t0
+    out["TSU_sample_boltzmann_QuadraticEnergy_dim_2^20"] = {"ms_per_call": dt * 1e3, "element_steps_per_s": (2 ** 20) * 500 / dt, "variance": float(x.var())}
+    t0 = time.perf_counter()
+    x = t.sample_boltzmann(lambda v: (v ** 2).sum(), n_samples=1, dim=2 ** 20)
+    dt = time.perf_counter() - t0
+    out["TSU_sample_boltzmann_lambda_dim_2^20"] = {"ms_per_call": dt * 1e3, "variance": float(x.var()),
+                                                   "note": "the README idiom with a Python callable: ~140 probing evaluations recognise the uniform quadratic, then K3"}
+    return out
 
 
 def time_sparse_chain(hip, ctx, counters, n=1 << 24):
@@ -247,6 +334,46 @@ def time_sparse_chain(hip, ctx, counters, n=1 << 24):
                          "note": "algorithmic 17 + 13 deg bytes per update (CSR gather kernel, deg = 2) = 361 MB per launch of one colour "
                                  "class (2^23 sites); traffic: PMC bytes per such launch (upper estimate, see profiles/counters.json)"},
             "M": m / n}
+
+
+def time_strong_slab(hip, SlabLattice, dist, torch, world, local_rank, backend, L, transport, steps, spx=32, k=8):
+    """BASELINE configs[3]: ONE L x L lattice (16384^2) in `world` row slabs, halo exchange every `spx` sweeps; every rank calls it,
+    the returned record is the same on all of them (max over ranks of the elapsed time)."""
+    rows_local = L // world
+    slab = SlabLattice(rows_local, L, periodic=True, sweeps_per_exchange=spx, seed=42, transport=transport)
+    slab.lat.set_kernel(hip.KERNEL_AUTO, k)
+    slab.randomize()
+    slab.set_model(1.0, 0.0, T_C, hip.MODE_PHYSICAL)
+    sps = 4 * spx
+    timeout = float(os.environ.get("TSU_COMM_TIMEOUT_S", "120"))
+
+    def barrier():
+        slab.synchronize(timeout)
+        torch.cuda.synchronize()
+        dist.barrier()
+
+    for _ in range(3):
+        slab.sweep(sps)
+    barrier()
+    ex0 = slab.n_exchanges
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        slab.sweep(sps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t[0])
+    s_, b_ = slab.observables()
+    n_ex = slab.n_exchanges - ex0
+    if slab.comm is not None:
+        slab.comm.close()
+    slab.lat.close()
+    ups = float(L) * L * sps * steps / elapsed
+    return {"value": ups, "unit": "spin-updates/s", "scaling": "strong", "n_gpus": world, "lattice": f"{L}x{L} in {world} slabs of {rows_local}x{L}",
+            "halo_transport": transport, "sweeps_per_exchange": spx, "sweeps_per_step": sps, "steps": steps, "ms_per_step": elapsed * 1e3 / steps,
+            "halo_exchanges": n_ex, "roofline_frac_per_gpu": 2.0 * ups / world / 1e9 / HBM_PEAK_GBS,
+            "M": s_ / (float(L) * L), "E_per_site": -b_ / (float(L) * L)}
 
 
 def build_parser():
@@ -331,10 +458,13 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        from datetime import timedelta
+        # (a rank that never arrives ends the run with an error after this long instead of holding the node)
+        pg_timeout = timedelta(seconds=float(os.environ.get("BENCH_PG_TIMEOUT_S", "300")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), timeout=pg_timeout)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=pg_timeout)
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus asked for {args.gpus}")
 
@@ -383,6 +513,7 @@ def main():
             slab.sweep(sps)
 
         def barrier():
+            slab.synchronize(float(os.environ.get("TSU_COMM_TIMEOUT_S", "120")))  # bounded: raises instead of hanging on a lost peer
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -398,6 +529,7 @@ def main():
     barrier()
     the_lattice = lat if world == 1 else slab.lat
     launches0 = the_lattice.launch_count()
+    exchanges0 = 0 if world == 1 else slab.n_exchanges
     ctx.timer_begin()  # HIP events on the stream the kernels are launched on
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -436,6 +568,17 @@ def main():
     else:
         s, b = slab.observables()
 
+    multi_extra = None
+    if world > 1 and not args.no_extra and not args.strong:
+        # BASELINE configs[3] in the same record: ONE 16384 x 16384 lattice cut into `world` row slabs (strong scaling), with both
+        # halo transports (torch.distributed point-to-point ops; the library's own RCCL calls below the C ABI)
+        multi_extra = {}
+        Ls = int(os.environ.get("BENCH_STRONG_L", "16384"))
+        if Ls % world == 0 and (Ls // world) >= 64:
+            slab.lat.close()
+            for transport in (("torch", "rccl") if backend == "nccl" else ("torch",)):
+                multi_extra[f"strong_L{Ls}_{transport}"] = time_strong_slab(hip, SlabLattice, dist, torch, world, local_rank, backend, Ls, transport,
+                                                                           steps=max(2, min(args.steps, 10)))
     if rank == 0:
         out = {
             "metric": "spin-updates/sec on L×L 2D Ising Gibbs sweep; achieved HBM GB/s vs peak",
@@ -444,6 +587,7 @@ def main():
             "dtype": "int8", "data": "synthetic (Philox i.i.d. +-1 start, seed 42)",
             "backend": backend if world > 1 else None, "ranks_seen": world, "gpus_requested": args.gpus,
             "halo_transport": (os.environ.get("BENCH_TRANSPORT", "torch") if world > 1 else None),
+            "halo_exchanges_in_timed_region": (slab.n_exchanges - exchanges0) if world > 1 else None,
             "config": {"workload": f"IsingModel2D {rows_local}x{L} per GPU at T_c=2.269185, J=1, h=0, periodic, checkerboard Gibbs sweep "
                                    "(BASELINE.json configs[1])", "L": L, "lattice_rows": rows_local * world, "lattice_cols": L,
                        "sweeps_per_step": sps, "sweeps_per_generation": k, "sweeps_per_launch": sweeps_per_launch_avg, "sweeps_per_exchange": spx if world > 1 else None,
@@ -462,6 +606,8 @@ def main():
             "observables": {"M": s / (float(rows_local) * L * world), "E_per_site": -b / (float(rows_local) * L * world),
                             "note": "physical mode, random start; u(T_c) = -sqrt(2) = -1.4142 is approached slowly (critical slowing down)"},
         }
+        if multi_extra is not None:
+            out["extra"] = multi_extra
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(L)
             out["cpu_reference_order"] = cpu_reference_order()
@@ -473,8 +619,8 @@ def main():
             # 2^25 sites: the largest lattice whose tiles all stay resident in LDS (256 tiles of 256 x 512)
             extra["ising2d_4096x8192"] = time_lattice(hip, ctx, 4096, 0, 240, cols=8192)
             # 8192^2: one 512 x 512 nibble-plane tile per CU, resident in LDS; 16384^2: 256 x 512 nibble tiles, 8 sweeps per launch
-            for L2 in (8192, 16384):
-                extra[f"ising2d_L{L2}"] = time_lattice(hip, ctx, L2, 0, 240)
+            extra["ising2d_L8192"] = time_lattice(hip, ctx, 8192, 0, 256, counters=counters, ckey="k1_resident_nib_L8192_s256")
+            extra["ising2d_L16384"] = time_lattice(hip, ctx, 16384, 0, 240, counters=counters, ckey="k1_tiled_nib_L16384_k8", sweeps_per_launch=8)
             # BASELINE configs[0], the reference's own CPU-runnable case (cpu_reference_order times its loop on the same lattice)
             extra["ising2d_32x32"] = time_lattice(hip, ctx, 32, 0, 20000)
             # a width that is not a multiple of 16 (the wrap falls inside an octet): IsingModel2D(1000)
@@ -486,6 +632,7 @@ def main():
             extra["langevin_dim_2^20"] = time_langevin(hip, ctx, counters)
             extra["dense_gibbs"] = time_dense(hip, ctx, counters)
             extra["sparse_chain_2^24"] = time_sparse_chain(hip, ctx, counters)
+            extra["python_surface_unbound"] = time_python_surface(hip, ctx)
             out["extra"] = extra
         print(json.dumps(out))
     if world > 1:

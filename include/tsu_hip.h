@@ -167,6 +167,10 @@ int tsu_comm_destroy(tsu_comm* comm);
 int tsu_ising2d_halo_exchange(tsu_ising2d* lat, tsu_comm* comm);
 /* values[i] <- sum over ranks (n <= 8; observables: sum of spins, sum over bonds); synchronises */
 int tsu_comm_allreduce_i64(tsu_comm* comm, int64_t* values, int n);
+/* Wait until everything issued on the context's stream (sweeps and halo exchanges) has finished, for at most timeout_s seconds:
+ * an exchange whose peer never arrives returns TSU_E_RCCL instead of blocking for ever (the caller leaves with a non-zero exit).
+ * *n_exchanges (may be NULL): halo exchanges issued by this communicator so far. */
+int tsu_comm_wait(tsu_comm* comm, double timeout_s, uint64_t* n_exchanges);
 
 /* ------------------------------------------------------------------ dense coupling matrix (K2)
  * Replaces GibbsSampler.gibbs_sweep / sample_boltzmann / compute_energy on a dense J

@@ -327,3 +327,63 @@ def test_large_dim_energy_callables_are_probed_in_bounded_time_or_refused():
     with pytest.raises(core.SamplingError, match="QuadraticEnergy"):
         tsu.sample_boltzmann(lambda x: (x ** 4).sum(), n_samples=2, dim=2 ** 16)
     assert time.perf_counter() - t0 < 5.0
+
+
+def test_frozen_arrays_skip_the_content_hash_and_thawed_ones_do_not(monkeypatch):
+    """J.setflags(write=False) on a data-owning array: nobody can edit it in place, so the device copy made from it is reused
+    without hashing 8 n^2 bytes per call (the reference idiom ``state = s.gibbs_sweep(state, J)`` at kernel speed); a writeable
+    array is hashed on every call, an in-place edit of it is seen, and a bulk edit slipped in by thaw / refreeze trips the sample."""
+    import numpy as np
+    from tsu import gibbs, _hip
+
+    class FakeSystem:
+        built = 0
+
+        def __init__(self, J, bias, dtype):
+            FakeSystem.built += 1
+            self.J = np.array(J)
+
+        def close(self):
+            pass
+
+    calls = {"n": 0}
+    real = gibbs._content_key
+
+    def counting(a):
+        calls["n"] += 1
+        return real(a)
+
+    monkeypatch.setattr(_hip, "DenseSystem", FakeSystem)
+    monkeypatch.setattr(gibbs, "_content_key", counting)
+    s = gibbs.GibbsSampler(seed=1)
+    J = np.random.default_rng(0).random((300, 300))
+    # writeable: hashed every call, one upload while unchanged, a new upload after an in-place edit
+    s._system(J, None)
+    s._system(J, None)
+    assert calls["n"] == 4 and FakeSystem.built == 1  # (J and bias keys per call)
+    J[3, 4] += 1.0
+    assert s._system(J, None).J[3, 4] == J[3, 4] and FakeSystem.built == 2
+    # frozen: hashed once, then O(1)
+    J.setflags(write=False)
+    n0 = calls["n"]
+    s._system(J, None)
+    s._system(J, None)
+    s._system(J, None)
+    assert calls["n"] == n0 + 2 and FakeSystem.built == 2
+    # a frozen VIEW of a writeable array is not trusted (its base can be edited)
+    K = np.random.default_rng(1).random((300, 300))
+    V = K.view()
+    V.setflags(write=False)
+    n0 = calls["n"]
+    s._system(V, None)
+    s._system(V, None)
+    assert calls["n"] == n0 + 4
+    # thaw, bulk edit, refreeze between two calls: the sample trips
+    s._system(J, None)
+    built = FakeSystem.built
+    s._system(J, None)
+    assert FakeSystem.built == built
+    J.setflags(write=True)
+    J *= 2.0
+    J.setflags(write=False)
+    assert s._system(J, None).J[0, 0] == J[0, 0] and FakeSystem.built == built + 1

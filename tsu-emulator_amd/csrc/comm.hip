@@ -12,6 +12,9 @@
 // stream (ordered with the sweep launches on that stream).  Order inside the group: send up, send down, receive from below,
 // receive from above, so that with two ranks (up == down) the first send pairs with the peer's first receive.
 #include <dlfcn.h>
+
+#include <chrono>
+#include <thread>
 #include <rccl/rccl.h>
 
 #include "ising2d.h"
@@ -21,7 +24,28 @@ struct tsu_comm {
     ncclComm_t comm;
     int rank, nranks;
     int64_t* d_red;  // device scratch of the all-reduce
+    hipEvent_t done;  // recorded behind the last group issued (tsu_comm_wait)
+    uint64_t n_exchanges;
 };
+
+// wait for everything issued on the context's stream so far, but never for ever: an RCCL group whose peer never arrives would hold
+// hipStreamSynchronize until somebody kills the process.  Event query with a deadline; on expiry the caller gets TSU_E_RCCL and is
+// expected to leave (the communicator is not usable afterwards).
+static int tsu_comm_bounded_wait(tsu_comm* c, double timeout_s, const char* what) {
+    tsu_ctx* ctx = c->ctx;
+    TSU_HIP_TRY(ctx, hipEventRecord(c->done, ctx->stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        const hipError_t q = hipEventQuery(c->done);
+        if (q == hipSuccess) return TSU_OK;
+        if (q != hipErrorNotReady) return tsu_fail(ctx, TSU_E_HIP, "%s: %s", what, hipGetErrorString(q));
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (dt > timeout_s)
+            return tsu_fail(ctx, TSU_E_RCCL, "%s: rank %d of %d waited %.0f s for its peers (exchange %llu): giving up", what, c->rank, c->nranks,
+                            timeout_s, (unsigned long long)c->n_exchanges);
+        if (spins > 1000) std::this_thread::sleep_for(std::chrono::microseconds(spins > 100000 ? 1000 : 20));
+    }
+}
 
 namespace {
 struct Rccl {
@@ -114,7 +138,8 @@ int tsu_comm_create(tsu_ctx* ctx, int nranks, int rank, const uint8_t id[128], t
         delete c;
         return tsu_fail(ctx, TSU_E_RCCL, "ncclCommInitRank(%d of %d): %s", rank, nranks, R.GetErrorString(r));
     }
-    if (hipMalloc(&c->d_red, 8 * sizeof(int64_t)) != hipSuccess) {
+    c->n_exchanges = 0;
+    if (hipMalloc(&c->d_red, 8 * sizeof(int64_t)) != hipSuccess || hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) {
         (void)R.CommDestroy(c->comm);
         delete c;
         return tsu_fail(ctx, TSU_E_NOMEM, "tsu_comm_create: hipMalloc failed");
@@ -129,8 +154,17 @@ int tsu_comm_destroy(tsu_comm* c) {
     (void)hipStreamSynchronize(c->ctx->stream);
     (void)rccl().CommDestroy(c->comm);
     (void)hipFree(c->d_red);
+    (void)hipEventDestroy(c->done);
     delete c;
     return TSU_OK;
+}
+
+int tsu_comm_wait(tsu_comm* c, double timeout_s, uint64_t* n_exchanges) {
+    TSU_ENTER(c ? c->ctx : nullptr);
+    if (!c) return TSU_E_INVALID;
+    TSU_REQUIRE(c->ctx, timeout_s > 0.0, "tsu_comm_wait: timeout must be positive");
+    if (n_exchanges) *n_exchanges = c->n_exchanges;
+    return tsu_comm_bounded_wait(c, timeout_s, "tsu_comm_wait");
 }
 
 int tsu_ising2d_halo_exchange(tsu_ising2d* L, tsu_comm* c) {
@@ -160,6 +194,7 @@ int tsu_ising2d_halo_exchange(tsu_ising2d* L, tsu_comm* c) {
     const ncclResult_t re = R.GroupEnd();
     if (r != ncclSuccess) return tsu_fail(ctx, TSU_E_RCCL, "ising2d_halo_exchange: %s", R.GetErrorString(r));
     TSU_RCCL_TRY(ctx, re);
+    c->n_exchanges += 1;
     return TSU_OK;
 }
 
@@ -171,8 +206,8 @@ int tsu_comm_allreduce_i64(tsu_comm* c, int64_t* values, int n) {
     TSU_HIP_TRY(ctx, hipMemcpyAsync(c->d_red, values, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     TSU_RCCL_TRY(ctx, rccl().AllReduce(c->d_red, c->d_red, (size_t)n, ncclInt64, ncclSum, c->comm, ctx->stream));
     TSU_HIP_TRY(ctx, hipMemcpyAsync(values, c->d_red, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-    TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return TSU_OK;
+    static const double timeout_s = getenv("TSU_COMM_TIMEOUT_S") ? atof(getenv("TSU_COMM_TIMEOUT_S")) : 120.0;
+    return tsu_comm_bounded_wait(c, timeout_s > 0 ? timeout_s : 120.0, "tsu_comm_allreduce_i64");
 }
 
 }  // extern "C"

@@ -79,6 +79,7 @@ SIGNATURES = {
     "tsu_comm_create": (C.c_int, [_vp, C.c_int, C.c_int, _u8p, C.POINTER(_vp)]),
     "tsu_comm_destroy": (C.c_int, [_vp]),
     "tsu_ising2d_halo_exchange": (C.c_int, [_vp, _vp]),
+    "tsu_comm_wait": (C.c_int, [_vp, C.c_double, _u64p]),
     "tsu_comm_allreduce_i64": (C.c_int, [_vp, _i64p, C.c_int]),
     "tsu_dense_create": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _f64p, C.POINTER(_vp)]),
     "tsu_dense_destroy": (C.c_int, [_vp]),
@@ -496,6 +497,12 @@ class Comm:
 
     def halo_exchange(self, lattice: "Lattice"):
         self.ctx.check(self.lib.tsu_ising2d_halo_exchange(lattice.h, self.h))
+
+    def wait(self, timeout_s=120.0):
+        """Bounded wait for the stream's sweeps and exchanges; returns the number of halo exchanges issued so far."""
+        n = C.c_uint64(0)
+        self.ctx.check(self.lib.tsu_comm_wait(self.h, float(timeout_s), C.byref(n)))
+        return int(n.value)
 
     def allreduce(self, values):
         v = np.ascontiguousarray(values, dtype=np.int64).copy()

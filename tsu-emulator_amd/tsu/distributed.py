@@ -61,6 +61,11 @@ class SlabLattice:
             raise ValueError(f"sweeps_per_exchange={self.k} needs {self.ghost} ghost rows but the slab has {self.rows}")
         self.seed = int(seed)
         self.sweep_count = 0
+        self.n_exchanges = 0  # halo exchanges issued so far (whatever the transport)
+        if overlap and transport == "rccl":
+            # tsu_ising2d_halo_exchange enqueues its RCCL group on the context's own stream: behind the interior launch, not beside it
+            raise ValueError("overlap=True needs transport='torch' (the library's RCCL transport runs on the compute stream: "
+                             "its exchange would queue behind the interior sweep instead of overlapping it)")
         self.up = (self.rank - 1) % self.world if (self.periodic or self.rank > 0) else None
         self.down = (self.rank + 1) % self.world if (self.periodic or self.rank < self.world - 1) else None
         # ghosts staged through host memory: test doubles, and torch's gloo backend -- unless the library's own RCCL transport
@@ -188,6 +193,7 @@ class SlabLattice:
             self.lat.set_spins(gbot.numpy(), row_first=R)
 
     def exchange(self):
+        self.n_exchanges += 1
         if self._host_staged:
             self._exchange_host()
         else:
@@ -256,6 +262,20 @@ class SlabLattice:
             return None
         return np.concatenate([p.cpu().numpy() for p in parts])
 
-    def synchronize(self):
-        if self.ctx is not None:
-            self.ctx.synchronize()
+    def synchronize(self, timeout_s: float = 120.0):
+        """Wait for this rank's sweeps and exchanges -- never for ever: a halo exchange whose peer does not arrive raises after
+        ``timeout_s`` (``TimeoutError`` / ``HipError``), so that a broken world ends with a non-zero exit instead of a hung node."""
+        if self.comm is not None:
+            self.comm.wait(timeout_s)
+            return
+        if self.ctx is None:
+            return
+        import time
+        ev = self.torch.cuda.Event()
+        ev.record(self.compute_stream)
+        t0 = time.monotonic()
+        while not ev.query():
+            if time.monotonic() - t0 > timeout_s:
+                raise TimeoutError(f"rank {self.rank} of {self.world}: sweeps / halo exchange {self.n_exchanges} did not finish within "
+                                   f"{timeout_s:.0f} s (a neighbouring rank never arrived?)")
+            time.sleep(0.0002)

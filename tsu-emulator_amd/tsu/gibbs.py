@@ -48,25 +48,65 @@ class GibbsConfig:
             raise ValueError("Update order must be 'sequential' or 'random'")
 
 
+_HASH_CHUNK = 1 << 24        # bytes per task of the parallel content hash
+_HASH_PARALLEL_MIN = 1 << 25  # buffers from 32 MiB on are hashed by a thread pool
+_hash_pool = None
+
+
+def _hash_bytes(buf) -> bytes:
+    try:
+        import xxhash
+        return xxhash.xxh3_128_digest(buf)
+    except ImportError:  # pragma: no cover - xxhash ships with the image
+        import hashlib
+        return hashlib.blake2b(buf, digest_size=16).digest()
+
+
 def _content_key(a: Optional[np.ndarray]):
     """Exact content key of a host array (shape, dtype, 128-bit hash of EVERY byte): decides whether the device copy of
     J / bias made by an earlier call may be reused.  The reference reads ``coupling`` afresh at every site
     (gibbs.py:97), so any in-place edit between two calls must be seen: the whole buffer is hashed, O(n^2) bytes once
-    per call (xxh3: ~10 GB/s), next to the O(n^2) work per sweep.  Callers with a hot loop over one unchanged J can
-    skip it explicitly with :meth:`GibbsSampler.bind`."""
+    per call next to the O(n^2) work per sweep.  Large buffers are hashed in 16 MiB chunks on a thread pool (xxh3 releases
+    the GIL; the key is the hash of the chunk digests): the 2 GiB of an N = 16384 float64 J take 0.33 s on one core and
+    1 / cores of that on the pool -- still two orders of magnitude more than a sweep, which is why callers with a hot loop
+    over one unchanged J either freeze it (``J.setflags(write=False)``: see :meth:`GibbsSampler._system`) or
+    :meth:`GibbsSampler.bind` it."""
     if a is None:
         return None
     a = np.ascontiguousarray(a)
     buf = a.reshape(-1).view(np.uint8) if a.dtype != object else None
     if buf is None:
         raise TypeError("coupling / bias must be numeric arrays")
-    try:
-        import xxhash
-        digest = xxhash.xxh3_128_digest(buf)
-    except ImportError:  # pragma: no cover - xxhash ships with the image
-        import hashlib
-        digest = hashlib.blake2b(buf, digest_size=16).digest()
+    if buf.nbytes >= _HASH_PARALLEL_MIN:
+        global _hash_pool
+        if _hash_pool is None:
+            import os
+            from concurrent.futures import ThreadPoolExecutor
+            _hash_pool = ThreadPoolExecutor(max_workers=max(2, min(32, len(os.sched_getaffinity(0)))), thread_name_prefix="tsu-hash")
+        parts = list(_hash_pool.map(_hash_bytes, [buf[o:o + _HASH_CHUNK] for o in range(0, buf.nbytes, _HASH_CHUNK)]))
+        digest = _hash_bytes(b"".join(parts))
+    else:
+        digest = _hash_bytes(buf)
     return (a.shape, a.dtype.str, digest)
+
+
+def _is_frozen(a) -> bool:
+    """A NumPy array whose bytes cannot be edited in place by anybody: it is not writeable and owns its buffer (no writeable base
+    or sibling view can reach it)."""
+    return a is None or (isinstance(a, np.ndarray) and not a.flags.writeable and a.flags.owndata)
+
+
+def _sample_key(a):
+    """64 windows of 4 KiB spread over the buffer, hashed: a tripwire for the one way a frozen array can still change (its owner
+    makes it writeable, edits it and freezes it again between two calls): bulk edits are caught, single entries are the owner's
+    responsibility (documented in :meth:`GibbsSampler._system`)."""
+    if a is None:
+        return None
+    buf = np.ascontiguousarray(a).reshape(-1).view(np.uint8)
+    if buf.nbytes <= (1 << 18):
+        return _hash_bytes(buf)
+    step = (buf.nbytes - 4096) // 63
+    return _hash_bytes(b"".join(bytes(buf[k * step:k * step + 4096]) for k in range(64)))
 
 
 class GibbsSampler:
@@ -87,6 +127,7 @@ class GibbsSampler:
         self._dtype = _hip.DTYPE_F64 if coupling_dtype == "float64" else _hip.DTYPE_F32
         self._bound = None  # (content key of J, content key of bias, DenseSystem)
         self._held = None   # (J object, bias object): arrays whose device copy is reused WITHOUT a content check
+        self._frozen = None  # (J object, bias object, sample keys): frozen arrays the device copy was made from (see _system)
         self._bound_sparse = None  # (content key of the CSR arrays and bias, SparseSystem)
 
     # ------------------------------------------------------------------ scalar helpers (host)
@@ -125,6 +166,7 @@ class GibbsSampler:
             self._bound[2].close()
         self._bound = None
         self._held = None
+        self._frozen = None
         if self._bound_sparse is not None:
             self._bound_sparse[1].close()
             self._bound_sparse = None
@@ -143,21 +185,35 @@ class GibbsSampler:
         self._held = None
 
     def _system(self, coupling: np.ndarray, bias: Optional[np.ndarray]) -> "_hip.DenseSystem":
+        """The device copy of (coupling, bias) to use for this call.  Three cases, from cheap to dear:
+
+        * :meth:`bind` named these very objects: reuse, no check (the caller's promise);
+        * the arrays are FROZEN -- ``coupling.setflags(write=False)`` on an array that owns its data (bias likewise or None) -- and
+          are the objects the device copy was made from: nobody can edit them in place, so the copy is current; O(1) plus a
+          256 KiB sampled tripwire.  (The owner could make the array writeable, edit and freeze it again between two calls: a bulk
+          edit trips the sample, a single entry does not -- whoever thaws an array calls :meth:`invalidate`.)  This is how the
+          reference idiom ``state = s.gibbs_sweep(state, J)`` loops at kernel speed without any API the reference lacks;
+        * otherwise every byte is hashed (the reference reads ``coupling`` afresh at every site, gibbs.py:97: an in-place edit
+          between two calls must be seen), in parallel from 32 MiB on."""
         if self._held is not None and self._bound is not None:
             if coupling is self._held[0] and bias is self._held[1]:
                 return self._bound[2]
-        coupling_in = coupling
+        if self._frozen is not None and self._bound is not None:
+            if coupling is self._frozen[0] and bias is self._frozen[1] and _is_frozen(coupling) and _is_frozen(bias):
+                if _sample_key(coupling) == self._frozen[2] and _sample_key(bias) == self._frozen[3]:
+                    return self._bound[2]
+        self._frozen = None
+        coupling_in, bias_in = coupling, bias
         coupling = np.asarray(coupling)
         if coupling.ndim != 2 or coupling.shape[0] != coupling.shape[1]:
             raise ValueError("Coupling matrix must be square")
         fj, fb = _content_key(coupling), _content_key(None if bias is None else np.asarray(bias))
-        if self._bound is not None and self._bound[0] == fj and self._bound[1] == fb:
-            return self._bound[2]
-        del coupling_in
-        self.invalidate()
-        sys = _hip.DenseSystem(coupling, bias, self._dtype)
-        self._bound = (fj, fb, sys)
-        return sys
+        if not (self._bound is not None and self._bound[0] == fj and self._bound[1] == fb):
+            self.invalidate()
+            self._bound = (fj, fb, _hip.DenseSystem(coupling, bias, self._dtype))
+        if isinstance(coupling_in, np.ndarray) and _is_frozen(coupling_in) and _is_frozen(bias_in):
+            self._frozen = (coupling_in, bias_in, _sample_key(coupling_in), _sample_key(bias_in))
+        return self._bound[2]
 
     @staticmethod
     def _as_bits(state: np.ndarray, n: int) -> np.ndarray:
