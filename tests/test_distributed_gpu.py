@@ -237,3 +237,78 @@ def _nccl_worker_abi(rank, world, port, q):
             q.put((full, obs))
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------ replicas over ranks (second half)
+def _replica_worker(rank, world, port, q, n, temps):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tsu-emulator_amd"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    from tsu.core import QuadraticEnergy, TSUConfig
+    from tsu.distributed import ReplicaLadder, sample_quadratic_sharded
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, device_id=torch.device(f"cuda:{rank}"))
+    try:
+        rng = np.random.default_rng(3)
+        J = rng.normal(size=(n, n)) / np.sqrt(n)
+        J = (J + J.T) / 2
+        np.random.seed(11)
+        lad = ReplicaLadder(J, temps, None, n_burnin=2, n_sweeps=2, seed=99)
+        lad.run(6, swap_interval=2)
+        samples, info = lad.samples(), lad.info()
+        lad.close()
+        cfg = TSUConfig(temperature=0.8, dt=0.02, n_burnin=20, n_steps=50)
+        x = sample_quadratic_sharded(QuadraticEnergy(2.0, 0.3), np.zeros(4096), 5, cfg, seed=5)
+        if rank == 0:
+            q.put((samples, info["swap_attempts"], info["swap_accepts"], x))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_replicas(world, n, temps):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_replica_worker, args=(r, world, port, q, n, temps)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    return got
+
+
+@pytest.mark.parametrize("n", [24, 2304])
+def test_tempering_ladder_and_sharded_langevin_on_an_rccl_group_of_one_rank(n):
+    """ReplicaLadder / sample_quadratic_sharded with the product engines under init_process_group("nccl") at world size 1 (all this
+    box can run: the all_gather of the energies and of the samples go through RCCL on cuda tensors) == GibbsSampler.parallel_tempering
+    / ThermalSamplingUnit.sample_from_energy in this process (same seeds, same np.random draws)."""
+    from tsu.core import QuadraticEnergy, ThermalSamplingUnit, TSUConfig
+    from tsu.gibbs import GibbsConfig, GibbsSampler
+    temps = [0.6, 0.9, 1.4, 2.1, 3.0]
+    samples, attempts, accepts, x = _run_replicas(1, n, temps)
+    rng = np.random.default_rng(3)
+    J = rng.normal(size=(n, n)) / np.sqrt(n)
+    J = (J + J.T) / 2
+    np.random.seed(11)
+    s = GibbsSampler(GibbsConfig(n_burnin=2, n_sweeps=2), seed=99)
+    want, info = s.parallel_tempering(J, temps, n_samples=6, swap_interval=2)
+    np.testing.assert_array_equal(samples, want)
+    assert (attempts, accepts) == (info["swap_attempts"], info["swap_accepts"])
+    t = ThermalSamplingUnit(TSUConfig(temperature=0.8, dt=0.02, n_burnin=20, n_steps=50), seed=5)
+    np.testing.assert_array_equal(x, t.sample_from_energy(QuadraticEnergy(2.0, 0.3), np.zeros(4096), n_samples=5))
+
+
+def test_tempering_ladder_two_ranks():
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    temps = [0.6, 0.9, 1.4, 2.1, 3.0]
+    a = _run_replicas(1, 2304, temps)
+    b = _run_replicas(2, 2304, temps)
+    np.testing.assert_array_equal(a[0], b[0])
+    assert a[1:3] == b[1:3]
+    np.testing.assert_array_equal(a[3], b[3])

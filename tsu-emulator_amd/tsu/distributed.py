@@ -279,3 +279,179 @@ class SlabLattice:
                 raise TimeoutError(f"rank {self.rank} of {self.world}: sweeps / halo exchange {self.n_exchanges} did not finish within "
                                    f"{timeout_s:.0f} s (a neighbouring rank never arrived?)")
             time.sleep(0.0002)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Replicas over ranks (second half): the sequential dense chain does not shard -- a column-sharded field would
+# need an all-reduce per block of sites -- but independent replicas do.  No collective on the sweep path; a tempering swap needs
+# two scalars per neighbouring pair (their energies).
+
+class ReplicaLadder:
+    """``GibbsSampler.parallel_tempering`` (reference: tsu/gibbs.py:238-338) with the replicas spread over the ranks of a process
+    group: rank r owns the chains [r m, (r + 1) m) of R = len(temperatures) (m = ceil(R / world)), all of them advanced by ONE launch
+    per step on that rank's GPU (``tsu_dense_sweep_replicas``: one stream of J for the rank's chains).
+
+    What moves between ranks is never a state: a swap exchanges the SLOTS of two chains (temperature, Philox seed and sweep counter
+    belong to the slot, as they belong to the reference's per-temperature sampler objects, gibbs.py:285-291), and deciding it
+    needs the two energies only -- one ``all_gather`` of one float64 per chain per swap round (the "2 scalars" of the survey).
+    Every rank draws the same ``np.random`` numbers (initial states, acceptance uniforms), so the slot bookkeeping is replicated
+    and the trajectory is the single-process one for any world size (tested on gloo with an oracle-backed double, world 1 / 2 / 3).
+    The sample of a step is the state in slot 0 (gibbs.py:326); its owner keeps it, ``samples()`` gathers them on every rank.
+
+    ``engine(coupling, bias)`` builds the per-rank dense system (default: :class:`tsu._hip.DenseSystem`; the CPU-only tests inject
+    a double with ``sweep_replicas`` / ``energies``, the product never does)."""
+
+    def __init__(self, coupling, temperatures, bias=None, n_burnin: int = 100, n_sweeps: int = 10, seed: Optional[int] = None,
+                 group=None, engine=None, coupling_dtype: str = "float64"):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if self.distributed else 0
+        self.world = dist.get_world_size(group) if self.distributed else 1
+        self.backend = dist.get_backend(group) if self.distributed else "none"
+        self.temperatures = [float(T) for T in temperatures]
+        for T in self.temperatures:
+            if T <= 0:
+                raise ValueError("Temperature must be positive")
+        self.R = len(self.temperatures)
+        coupling = np.asarray(coupling)
+        if coupling.ndim != 2 or coupling.shape[0] != coupling.shape[1]:
+            raise ValueError("Coupling matrix must be square")
+        self.n = coupling.shape[0]
+        self.n_burnin, self.n_sweeps = int(n_burnin), int(n_sweeps)
+        m = -(-self.R // self.world)
+        self.mine = list(range(min(self.R, self.rank * m), min(self.R, (self.rank + 1) * m)))  # chains this rank owns
+        self.owner = [min(c // m, self.world - 1) for c in range(self.R)]
+        # replicated bookkeeping (identical on every rank): the reference's draws in its order
+        if seed is None:
+            seed = int(np.random.randint(0, 2 ** 31 - 1)) | (int(np.random.randint(0, 2 ** 31 - 1)) << 31)
+        self.seed = int(seed)
+        states = [np.random.randint(0, 2, size=self.n) for _ in range(self.R)]  # gibbs.py:282 (every rank draws all, keeps its own)
+        self.slot_of = list(range(self.R))          # chain c sits in slot slot_of[c]
+        self.chain_in = list(range(self.R))         # slot i holds chain chain_in[i]
+        self.slot_seed = [self.seed + i + 1 for i in range(self.R)]   # as GibbsSampler.parallel_tempering seeds its per-slot samplers
+        self.slot_sweeps = [0] * self.R
+        if engine is None:
+            dt = _hip.DTYPE_F64 if coupling_dtype == "float64" else _hip.DTYPE_F32
+            self.sys = _hip.DenseSystem(coupling, bias, dt)
+        else:
+            self.sys = engine(coupling, bias)
+        self.states = np.array([states[c] for c in self.mine], dtype=np.int8).reshape(len(self.mine), self.n)
+        self._samples = {}   # step -> state of slot 0 (on the rank that owned it at that step)
+        self.steps = 0
+        self.swap_attempts = self.swap_accepts = 0
+        self.energies_history = [[] for _ in range(self.R)]
+
+    # ---- one launch per call on every rank
+    def _sweep(self, n_sweeps: int):
+        if n_sweeps <= 0:
+            return
+        if self.mine:
+            slots = [self.slot_of[c] for c in self.mine]
+            self.states = np.asarray(self.sys.sweep_replicas(self.states, [self.temperatures[i] for i in slots], n_sweeps,
+                                                             [self.slot_seed[i] for i in slots], [self.slot_sweeps[i] for i in slots]),
+                                     dtype=np.int8).reshape(len(self.mine), self.n)
+        for i in range(self.R):
+            self.slot_sweeps[i] += n_sweeps
+
+    def _all_energies(self) -> np.ndarray:
+        """Energy of every chain, indexed by chain: each rank evaluates its own, one all_gather of m float64."""
+        m = -(-self.R // self.world)
+        local = np.zeros(m)
+        if self.mine:
+            local[:len(self.mine)] = self.sys.energies(self.states)
+        if not self.distributed:
+            return local[:self.R]
+        t = self.torch.from_numpy(local)
+        if self.backend == "nccl":
+            t = t.cuda()
+        parts = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(parts, t, group=self.group)
+        return np.concatenate([p.cpu().numpy() for p in parts])[:self.R]
+
+    def run(self, n_samples: int, swap_interval: int = 10):
+        """The reference's loop (gibbs.py:293-327): burn-in, then per step n_sweeps sweeps of every replica, an energy record, every
+        ``swap_interval`` steps a round of neighbour swaps, and the state of slot 0 as the step's sample."""
+        self._sweep(self.n_burnin)
+        for _ in range(int(n_samples)):
+            self._sweep(self.n_sweeps)
+            e = self._all_energies()
+            for i in range(self.R):
+                self.energies_history[i].append(float(e[self.chain_in[i]]))
+            self.steps += 1
+            if self.steps % swap_interval == 0:
+                for i in range(self.R - 1):
+                    ci, cj = self.chain_in[i], self.chain_in[i + 1]
+                    delta = (1.0 / self.temperatures[i] - 1.0 / self.temperatures[i + 1]) * (e[cj] - e[ci])
+                    self.swap_attempts += 1
+                    if delta >= 0 or np.random.rand() < np.exp(delta):  # gibbs.py:317-323, the same draw on every rank
+                        self.chain_in[i], self.chain_in[i + 1] = cj, ci
+                        self.slot_of[ci], self.slot_of[cj] = i + 1, i
+                        self.swap_accepts += 1
+            c0 = self.chain_in[0]
+            if c0 in self.mine:
+                self._samples[self.steps - 1] = self.states[self.mine.index(c0)].copy()
+        return self
+
+    def samples(self) -> np.ndarray:
+        """(n_steps, n) states of slot 0, on every rank (one all_gather_object at the end of a run, not per step)."""
+        if not self.distributed:
+            merged = self._samples
+        else:
+            parts = [None] * self.world
+            self.dist.all_gather_object(parts, self._samples, group=self.group)
+            merged = {}
+            for p in parts:
+                merged.update(p)
+        return np.array([merged[k] for k in range(self.steps)], dtype=np.int64).reshape(self.steps, self.n)
+
+    def info(self) -> dict:
+        return {"swap_acceptance_rate": self.swap_accepts / self.swap_attempts if self.swap_attempts else 0,
+                "swap_attempts": self.swap_attempts, "swap_accepts": self.swap_accepts, "energies": self.energies_history}
+
+    def close(self):
+        if hasattr(self.sys, "close"):
+            self.sys.close()
+
+
+def sample_quadratic_sharded(q, x_init, n_samples: int, config, seed: int, group=None, engine=None, chain0: int = 0) -> np.ndarray:
+    """``ThermalSamplingUnit.sample_from_energy`` for a separable quadratic energy (reference: tsu/core.py:100-162: ``n_samples``
+    independent restarts of one Langevin chain) with the restarts sharded over the ranks: rank r runs the chains
+    [r m, (r + 1) m) on its GPU (K3, all steps fused) and one ``all_gather`` brings the samples to every rank.  No collective
+    inside the chain loop.  The Philox stream is keyed by the GLOBAL chain number, so the samples do not depend on the world size
+    (tested on gloo, world 1 / 2 / 3, and against the single-process path).  ``engine(n_chains, dim)``: the per-rank chain set
+    (default :class:`tsu._hip.LangevinChains`; CPU-only tests inject an oracle-backed double)."""
+    import torch
+    import torch.distributed as dist
+    distributed = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank(group) if distributed else 0
+    world = dist.get_world_size(group) if distributed else 1
+    backend = dist.get_backend(group) if distributed else "none"
+    x0 = np.atleast_1d(np.asarray(x_init, dtype=np.float64))
+    d = x0.size
+    m = -(-int(n_samples) // world)
+    lo, hi = min(n_samples, rank * m), min(n_samples, (rank + 1) * m)
+    local = np.zeros((m, d), dtype=np.float32)
+    if hi > lo:
+        lc = (engine or _hip.LangevinChains)(hi - lo, d)
+        try:
+            lc.set_energy(np.broadcast_to(q.k, (d,)).astype(np.float32), np.broadcast_to(q.mu, (d,)).astype(np.float32))
+            lc.restart(x0.astype(np.float32), 0.1, seed, chain0 + lo)   # x_init + 0.1 N(0,1) (core.py:142-143) ...
+            if lo == 0:                                                # ... except sample 0, which starts exactly at x_init
+                st = lc.get_state()
+                st[0] = x0.astype(np.float32)
+                lc.set_state(st)
+            lc.step(int(config.n_burnin), config.dt, config.friction, config.temperature, seed, 0, chain0 + lo)
+            lc.step(int(config.n_steps), config.dt, config.friction, config.temperature, seed, int(config.n_burnin), chain0 + lo)
+            local[:hi - lo] = lc.get_state()
+        finally:
+            lc.close()
+    if not distributed:
+        return local[:n_samples].astype(np.float64)
+    t = torch.from_numpy(local)
+    if backend == "nccl":
+        t = t.cuda()
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t, group=group)
+    return np.concatenate([p.cpu().numpy() for p in parts])[:n_samples].astype(np.float64)
