@@ -71,6 +71,8 @@ def test_sparse_create_rejects_bad_input():
     g = _hip.SparseSystem(A.indptr, A.indices, A.data, None, off, order)
     with pytest.raises(ValueError, match="Temperature must be positive"):
         g.sweep(0.0, 1)
+    with pytest.raises(ValueError, match="state must be 0/1"):  # like the dense path: no other int8 value may reach the fields
+        g.set_state(np.array([0, 1, 2, 0, 1, 0], np.int8))
     g.close()
 
 

@@ -574,19 +574,25 @@ static hipError_t k2wg_launch(const tsu_dense* d, hipStream_t stream, const doub
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void k2_energy(const double* __restrict__ f, const int8_t* __restrict__ s,
-                                                const double* __restrict__ bias, double* __restrict__ out, int n) {
-    // f = J s + b  =>  -1/2 s.(f - b) - b.s
-    __shared__ double part[4];
+__global__ __launch_bounds__(1024) void k2_energy(const double* __restrict__ f, const int8_t* __restrict__ s,
+                                                 const double* __restrict__ bias, double* __restrict__ out, int n) {
+    // f = J s + b  =>  -1/2 s.(f - b) - b.s.  ONE workgroup, sums in a fixed order (strided per thread, a shuffle tree per wave, the
+    // sixteen waves in order): two evaluations of the same state give the same bits, so that comparisons between states of
+    // equal energy (simulated_annealing's running minimum, gibbs.py:384-391) do not depend on the order in which atomics land
+    __shared__ double part[16];
     double acc = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (int i = threadIdx.x; i < n; i += 1024) {
         double b = bias ? bias[i] : 0.0, si = (double)s[i];
         acc += -0.5 * si * (f[i] - b) - b * si;
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < 16; ++w) tot += part[w];
+        *out = tot;
+    }
 }
 
 // ================================================================== superblock fixed-point resolve
@@ -1300,10 +1306,7 @@ int tsu_dense_energy(tsu_dense* d, double* energy) {
         else
             k2_matvec<float><<<mv_grid, 256, 0, ctx->stream>>>((const float*)d->J, d->state, d->bias, d->field, d->n);
     }
-    TSU_HIP_TRY(ctx, hipMemsetAsync(d->d_energy, 0, 8, ctx->stream));
-    int blocks = (d->n + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
-    k2_energy<<<blocks, 256, 0, ctx->stream>>>(fields, d->state, d->bias, d->d_energy, d->n);
+    k2_energy<<<1, 1024, 0, ctx->stream>>>(fields, d->state, d->bias, d->d_energy, d->n);
     TSU_HIP_TRY(ctx, hipGetLastError());
     TSU_HIP_TRY(ctx, hipMemcpyAsync(energy, d->d_energy, 8, hipMemcpyDeviceToHost, ctx->stream));
     TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1339,15 +1342,13 @@ int tsu_dense_energies(tsu_dense* d, const int8_t* states_host, int n_states, do
     hipError_t e = hipMemcpyAsync(d->samples, states_host, n * (size_t)n_states, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_e, 0, (size_t)n_states * 8, ctx->stream);
     const unsigned mv_grid = (unsigned)((n * 64 + 255) / 256);
-    int blocks = (int)((n + 255) / 256);
-    if (blocks > 1024) blocks = 1024;
     for (int k = 0; k < n_states && e == hipSuccess; ++k) {  // one pass over J per state, all on the stream, one wait at the end
         const int8_t* s = d->samples + (size_t)k * n;
         if (d->dtype == TSU_DTYPE_F64)
             k2_matvec<double><<<mv_grid, 256, 0, ctx->stream>>>((const double*)d->J, s, d->bias, d->field, d->n);
         else
             k2_matvec<float><<<mv_grid, 256, 0, ctx->stream>>>((const float*)d->J, s, d->bias, d->field, d->n);
-        k2_energy<<<blocks, 256, 0, ctx->stream>>>(d->field, s, d->bias, d_e + k, d->n);
+        k2_energy<<<1, 1024, 0, ctx->stream>>>(d->field, s, d->bias, d_e + k, d->n);
     }
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(energies_host, d_e, (size_t)n_states * 8, hipMemcpyDeviceToHost, ctx->stream);

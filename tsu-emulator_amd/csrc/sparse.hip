@@ -247,6 +247,7 @@ int tsu_sparse_set_state(tsu_sparse* g, const int8_t* bits_host) {
     if (!g) return TSU_E_INVALID;
     tsu_ctx* ctx = g->ctx;
     TSU_REQUIRE(ctx, bits_host, "tsu_sparse_set_state: NULL buffer");
+    for (int i = 0; i < g->n; ++i) TSU_REQUIRE(ctx, bits_host[i] == 0 || bits_host[i] == 1, "sparse_set_state: state must be 0/1");
     TSU_HIP_TRY(ctx, hipMemcpyAsync(g->staging, bits_host, (size_t)g->n, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k5_scatter, dim3((unsigned)((g->n + 255) / 256)), dim3(256), 0, ctx->stream, g->staging, g->site_of, g->state, g->n);
     TSU_HIP_TRY(ctx, hipGetLastError());
