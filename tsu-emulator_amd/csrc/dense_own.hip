@@ -32,6 +32,9 @@
                                 // OWN_RING superblocks, checked by the host)
 #define OWN_TAG_SPAN 16384u     // generation g of superblock number q carries tag q * SPAN + g + 1 (0 = never written)
 #define OWN_MAX_R 8
+#ifndef OWN_REP_QUAD
+#define OWN_REP_QUAD 0          // replicas: 0 = one row per lane, scalar multipliers (own_axpy_rep); 1 = the quad layout in groups of four replicas
+#endif
 #define OWN_NGEN 16            // generation buffers (a ring by generation number): the deciders of a superblock move in lockstep and need two;
                                 // the FOLLOWERS (below) read the same buffers without being waited for and may lag up to OWN_NGEN - 2 generations
                                 // (they notice an overwritten buffer by its tag and fail the call -- the caller's other paths redo it)
@@ -127,7 +130,7 @@ static __device__ __forceinline__ void own_axpy_range(const TJ* __restrict__ JT,
 #pragma unroll
         for (int m = 0; m < 4; ++m) v[m] = xq.get(m);
         if (MODE == 2) {
-            const double sg = (code & 1u) ? ((code & 2u) ? -1.0 : 1.0) : 0.0;
+            const double sg = (double)(((int)(ev << 14)) >> 30);
             const int pj = pos[j];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -141,8 +144,8 @@ static __device__ __forceinline__ void own_axpy_range(const TJ* __restrict__ JT,
             }
 #pragma unroll
             for (int rho = 0; rho < RN; ++rho) {
-                const uint32_t c = (code >> (2 * (R0 + rho))) & 3u;
-                const double sg = (c & 1u) ? ((c & 2u) ? -1.0 : 1.0) : 0.0;
+                // (the 2-bit code, sign-extended, IS the multiplier: 01b = +1, 11b = -1, 00b = 0)
+                const double sg = (double)(((int)(ev << (14 - 2 * (R0 + rho)))) >> 30);
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc[rho][m] += sg * v[m];
             }
@@ -223,7 +226,7 @@ static __device__ __forceinline__ void own_axpy(const TJ* __restrict__ JT, int n
 template <typename TJ, int R, bool MASKED, int NA>
 static __device__ __forceinline__ void own_axpy_rep(const TJ* __restrict__ JT, int n, const uint32_t* lst, int nl, int col, int myrow, double* red,
                                                     int lane, int wv) {
-    constexpr int U = 8;
+    constexpr int U = 16;  // entries (256-byte segments) in flight per wave
     double acc[R];
 #pragma unroll
     for (int rho = 0; rho < R; ++rho) acc[rho] = 0.0;
@@ -248,8 +251,7 @@ static __device__ __forceinline__ void own_axpy_rep(const TJ* __restrict__ JT, i
 #pragma unroll
                 for (int rho = 0; rho < R; ++rho) {
                     // (a scalar multiplier: written as a branch the compiler turns the skip into five selects per replica)
-                    const uint32_t c = (ev >> (16 + 2 * rho)) & 3u;
-                    const double sg = c ? ((c & 2u) ? -1.0 : 1.0) : 0.0;
+                    const double sg = (double)(((int)(ev << (14 - 2 * rho))) >> 30);  // the 2-bit code, sign-extended: +1, -1 or 0
                     acc[rho] = fma(sg, v, acc[rho]);
                 }
             }
@@ -264,7 +266,8 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
     static_assert(!ORD || R == 1, "replicas advance in natural order only");
     constexpr int RW = 64 * M;           // sites per workgroup
     constexpr int NA = ORD ? 2 : R;      // accumulator slots of the axpy pass
-    constexpr int PW = M;                // the wave that polls and builds the lists (the first one that owns no rows)
+    constexpr int ND = R > 1 ? R : M;    // deciding waves: one per 64 rows (M of them), or -- several replicas, M = 1 -- one per replica
+    constexpr int PW = ND;               // the wave that polls and builds the lists (the first one that decides nothing)
     extern __shared__ unsigned long long own_lds[];
     __shared__ int s_nl, s_nlo, s_nle, s_fail;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -283,25 +286,28 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
     double* dL = dC + R * M * 64;               //   logit of the uniform,
     double* dA = dL + R * M * 64;               //   (ORD) the running field's change inside the current superblock  [M][64]
     unsigned short* pos = (unsigned short*)(dA + M * 64);        // (ORD) [n] position of every site in this sweep's order
-#define OWN_AT(rho) (((rho) * M + wv) * 64 + lane)
+#define OWN_AT(rho) (((rho) * M + (R > 1 ? 0 : wv)) * 64 + lane)
+// the replicas a deciding wave handles: all of them (one replica), or its own (wave = replica)
+#define OWN_FOR_RHO(rho) for (int rho = (R > 1 ? wv : 0); rho < (R > 1 ? wv + 1 : 1); ++rho)
 
     const int r0 = w * RW;
     const int myrow = r0 + 4 * (lane % (16 * M));       // the axpy pass: this lane's quad of rows myrow .. myrow + 3
     const int col0 = myrow + 4 <= n ? myrow : n - 4;    // (n is a multiple of 4: whole quads; lanes beyond n read the last one, unused)
-    const bool decider = wv < M;                        // wave e < M, lane l decides site r0 + 64 e + l
-    const int site = r0 + 64 * (decider ? wv : 0) + lane;
+    const bool decider = wv < ND;                       // wave e < M, lane l decides site r0 + 64 e + l (replicas: wave = replica, site r0 + l)
+    const int drow = (decider && R == 1) ? wv : 0;      // my 64-row group inside the workgroup
+    const int site = r0 + 64 * drow + lane;
     const bool site_ok = decider && site < n;
-    const int mygroup = w * M + (decider ? wv : 0);
+    const int mygroup = w * M + drow;
     if (threadIdx.x == 0) s_fail = 0;
     // the axpy pass in the layout that suits the replica count (see own_axpy / own_axpy_rep)
 #define OWN_AXPY_ALL(nl_)                                                                                        \
     do {                                                                                                         \
-        if (R > 1) own_axpy_rep<TJ, R, false, NA>(JT, n, lst, (nl_), rcol, r0 + lane, red, lane, wv);            \
+        if (R > 1 && !OWN_REP_QUAD) own_axpy_rep<TJ, R, false, NA>(JT, n, lst, (nl_), rcol, r0 + lane, red, lane, wv); \
         else own_axpy<TJ, M, R, 0, NA>(JT, n, lst, 0, (nl_), col0, myrow, pos, mypos, red, lane, wv);            \
     } while (0)
 #define OWN_AXPY_GEN(nlo_, nle_)                                                                                 \
     do {                                                                                                         \
-        if (R > 1) own_axpy_rep<TJ, R, true, NA>(JT, n, lst, (nle_), rcol, r0 + lane, red, lane, wv);            \
+        if (R > 1 && !OWN_REP_QUAD) own_axpy_rep<TJ, R, true, NA>(JT, n, lst, (nle_), rcol, r0 + lane, red, lane, wv);  \
         else own_axpy<TJ, M, R, 1, NA>(JT, n, lst, (nlo_), (nle_), col0, myrow, pos, mypos, red, lane, wv);      \
     } while (0)
     const int rcol = r0 + lane < n ? r0 + lane : n - 1;  // (replica layout: lane = row)
@@ -446,14 +452,13 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
     // ---- the rows' owners: field, correction, logit and committed value per replica ------------------------------------------
     int vcur = 0;    // committed value of my site, bit rho
     if (decider) {
-#pragma unroll
-        for (int rho = 0; rho < R; ++rho) {
+        OWN_FOR_RHO(rho) {
             dF[OWN_AT(rho)] = 0.0;
             dC[OWN_AT(rho)] = 0.0;
             dL[OWN_AT(rho)] = 0.0;
             vcur |= (int)((vmask[rho * G + mygroup] >> lane) & 1ull) << rho;
         }
-        dA[wv * 64 + lane] = 0.0;
+        dA[drow * 64 + lane] = 0.0;
     }
     int mypos[4];  // (ORD) positions of this lane's axpy rows
 #pragma unroll
@@ -463,7 +468,7 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
     auto reduced = [&](int a) -> double {
         double tot = 0.0;
 #pragma unroll
-        for (int u = 0; u < OWN_WAVES; ++u) tot += red[(u * NA + a) * RW + 64 * wv + lane];
+        for (int u = 0; u < OWN_WAVES; ++u) tot += red[(u * NA + a) * RW + 64 * drow + lane];
         return tot;
     };
 
@@ -486,8 +491,7 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                 if (site_ok) dF[OWN_AT(0)] = P.fields_all[site];
             } else {
                 if (decider) {
-#pragma unroll
-                    for (int rho = 0; rho < R; ++rho) dF[OWN_AT(rho)] = (site_ok && P.bias) ? P.bias[site] : 0.0;
+                    OWN_FOR_RHO(rho) dF[OWN_AT(rho)] = (site_ok && P.bias) ? P.bias[site] : 0.0;
                 }
                 const int lch = LMAX / 64;  // groups per list
                 for (int g0 = 0; g0 < G; g0 += lch) {
@@ -498,8 +502,7 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                     OWN_AXPY_ALL(nl);
                     __syncthreads();
                     if (decider) {
-#pragma unroll
-                        for (int rho = 0; rho < R; ++rho) dF[OWN_AT(rho)] += reduced(rho);
+                        OWN_FOR_RHO(rho) dF[OWN_AT(rho)] += reduced(rho);
                     }
                     __syncthreads();  // red and the list are rewritten
                 }
@@ -516,14 +519,13 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                 // (per-replica parameters are read where they are used: eight replicas' worth of them hoisted here cost 200 scalar spills)
 #define OWN_UNI(rho) (P.uniforms ? P.uniforms + ((size_t)(rho) * P.n_sweeps + sw) * n : nullptr)
 #define OWN_TW(rho) (P.temps ? P.temps[sw] : P.rep[rho].T)
-#pragma unroll
-                for (int rho = 0; rho < R; ++rho) {
+                if (decider) OWN_FOR_RHO(rho) {
                     if (mine)
                         dL[OWN_AT(rho)] = own_logit((uint32_t)site, (uint32_t)dpos, OWN_UNI(rho), P.rep[rho].sweep0 + (uint32_t)sw, P.rep[rho].tag, P.rep[rho].k0,
                                                     P.rep[rho].k1);
-                    if (decider) dC[OWN_AT(rho)] = 0.0;
+                    dC[OWN_AT(rho)] = 0.0;
                 }
-                if (decider) dA[wv * 64 + lane] = 0.0;
+                if (decider && ORD) dA[drow * 64 + lane] = 0.0;
                 // the running generation starts from the committed values
                 for (int q = (int)threadIdx.x; q < R * np; q += OWN_THREADS) {
                     const int rho = q / np, k = q - rho * np;
@@ -537,8 +539,7 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                     const unsigned tag = seq * OWN_TAG_SPAN + gi + 1u;
                     unsigned long long* gbuf = P.gen + (size_t)(gi % OWN_NGEN) * R * G * 2;
                     if (decider) {
-#pragma unroll
-                        for (int rho = 0; rho < R; ++rho) {
+                        OWN_FOR_RHO(rho) {
                             int v = (vcur >> rho) & 1;
                             if (mine) {
                                 const double Tw = OWN_TW(rho);
@@ -552,8 +553,15 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                         }
                     }
                     if (wv == PW) {
+                        const bool ptiming = P.timeline && w == W - 1 && lane == 0 && gi > 0;
+                        const long long p0_ = ptiming ? wall_clock64() : 0;
                         poll(gbuf, tag, g_lo, np, false);
+                        const long long p1_ = ptiming ? wall_clock64() : 0;
                         build_list(nm, NP, gm, NP, g_lo, np, true);
+                        if (ptiming) {
+                            tl[10] += (unsigned long long)(p1_ - p0_);
+                            tl[11] += (unsigned long long)(wall_clock64() - p1_);
+                        }
                     }
                     __syncthreads();
                     if (s_fail) return;
@@ -570,10 +578,9 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                     if (decider) {
                         if (ORD) {
                             dC[OWN_AT(0)] += reduced(0);
-                            dA[wv * 64 + lane] += reduced(1);
+                            dA[drow * 64 + lane] += reduced(1);
                         } else {
-#pragma unroll
-                            for (int rho = 0; rho < R; ++rho) dC[OWN_AT(rho)] += reduced(rho);
+                            OWN_FOR_RHO(rho) dC[OWN_AT(rho)] += reduced(rho);
                         }
                     }
                     OWN_MARK(gi == 0 ? 8 : 2);
@@ -589,8 +596,7 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                 if (P.samples && sw + 1 > P.rec_from && (sw + 1 - P.rec_from) % P.rec_every == 0)
                     rec = P.samples + (size_t)((sw + 1 - P.rec_from) / P.rec_every - 1) * n;
                 if (decider) {
-#pragma unroll
-                    for (int rho = 0; rho < R; ++rho) {
+                    OWN_FOR_RHO(rho) {
                         const int v = (vnew >> rho) & 1;
                         if (mine) {
                             P.state[(size_t)rho * n + site] = (int8_t)v;
@@ -607,7 +613,7 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                 }
                 if (ORD) {
                     // every workgroup followed every generation: the running field is current
-                    if (decider) dF[OWN_AT(0)] += dA[wv * 64 + lane];
+                    if (decider) dF[OWN_AT(0)] += dA[drow * 64 + lane];
                     for (int q = (int)threadIdx.x; q < np; q += OWN_THREADS) vmask[q] = gm[q];
                     __syncthreads();
                 } else {
@@ -621,8 +627,7 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                     OWN_AXPY_ALL(nl);
                     __syncthreads();
                     if (decider) {
-#pragma unroll
-                        for (int rho = 0; rho < R; ++rho) dF[OWN_AT(rho)] += reduced(rho);
+                        OWN_FOR_RHO(rho) dF[OWN_AT(rho)] += reduced(rho);
                     }
                     __syncthreads();
                 }
@@ -654,8 +659,7 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                         OWN_AXPY_ALL(nl);
                         __syncthreads();
                         if (decider) {
-#pragma unroll
-                            for (int rho = 0; rho < R; ++rho) dF[OWN_AT(rho)] += reduced(rho);
+                            OWN_FOR_RHO(rho) dF[OWN_AT(rho)] += reduced(rho);
                         }
                         if (gi + 3u >= OWN_TAG_SPAN) return;  // (the deciders have failed the call)
                     }
@@ -681,8 +685,7 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                     OWN_AXPY_ALL(nl);
                     __syncthreads();
                     if (decider) {
-#pragma unroll
-                        for (int rho = 0; rho < R; ++rho) dF[OWN_AT(rho)] += reduced(rho);
+                        OWN_FOR_RHO(rho) dF[OWN_AT(rho)] += reduced(rho);
                     }
                     __syncthreads();
                     OWN_MARK(7);
@@ -695,6 +698,7 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
         for (int x = 0; x < 12; ++x) P.timeline[x] = tl[x];
 #undef OWN_MARK
 #undef OWN_AT
+#undef OWN_FOR_RHO
 #undef OWN_AXPY_ALL
 #undef OWN_UNI
 #undef OWN_TW
@@ -832,9 +836,9 @@ int tsu_dense_own_run(tsu_dense* d, int R_real, const OwnRep* reps, int8_t* stat
         (void)hipFree(d_tl);
         const double per = (double)n_sweeps * (ord ? nsb : 1);  // the timed workgroup is active once per sweep in natural order
         fprintf(stderr, "[tsu] k2_own n=%d R=%d M=%d %s, superblocks of %d, %d sweeps; last workgroup, per active superblock: prologue %.1f us, first poll %.1f us, first axpy %.1f us, "
-                        "later polls %.1f us, later axpy+decide %.1f us, commit+strip %.1f us, %.1f generations, %.0f toggles; per sweep as a bystander: wait %.1f us, strips %.1f us\n",
+                        "later polls %.1f us, later axpy+decide %.1f us, commit+strip %.1f us, %.1f generations, %.0f toggles (later generations, poller wave: polling %.1f us, list building %.1f us); per sweep as a bystander: wait %.1f us, strips %.1f us\n",
                 n, R, M, ord ? "caller's order" : "natural order", sbw * RW, n_sweeps, tl[0] / 100.0 / per, tl[9] / 100.0 / per, tl[8] / 100.0 / per, tl[1] / 100.0 / per, tl[2] / 100.0 / per,
-                tl[3] / 100.0 / per, tl[4] / per, tl[5] / per, tl[6] / 100.0 / n_sweeps, tl[7] / 100.0 / n_sweeps);
+                tl[3] / 100.0 / per, tl[4] / per, tl[5] / per, tl[10] / 100.0 / per, tl[11] / 100.0 / per, tl[6] / 100.0 / n_sweeps, tl[7] / 100.0 / n_sweeps);
     }
     if (h[1] || h[3]) {
         fprintf(stderr, "[tsu] dense sweep (owner kernel): %s; continuing on the other paths\n", h[1] ? "a wait timed out (GPU shared?)" : "no fixed point");
