@@ -229,8 +229,9 @@ def time_dense(hip, ctx, counters, n=16384):
     out = {"N": n, "dtype": "f32", "ms_per_sweep": ms, "spin_updates_per_s": n / (ms * 1e-3), "J_stream_GBps": gbs,
            "kernel": "k2_own" if own else "k2_pipe", "launches": {"k2_own": own, "k2_pipe": pipe},
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                        "traffic": e.get("hbm_bytes"),
-                        "note": "algorithmic N^2 x 4 B per sweep (J streamed once) / time per sweep; k2_own reads only the rows of J^T of "
+                        "traffic": e.get("hbm_bytes_per_sweep_steady"),
+                        "note": "per SWEEP: algorithmic N^2 x 4 B (J streamed once) / time per sweep; traffic = PMC bytes per sweep of a lone launch "
+                                "of 8 sweeps without its field pass ((5.22 - 0.54) GB / 8); k2_own reads only the rows of J^T of "
                                 "the sites whose value changes (~41 % flip per sweep at T = 1, plus the toggles of the generations), so "
                                 "the PMC traffic per sweep is BELOW the algorithmic bytes (profiles/r03_pmc_k2_own_N16384_f32.txt)"}}
     # update_order="random": the caller's permutation per sweep (uploaded with the call; validated on the host)

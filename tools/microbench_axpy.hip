@@ -198,6 +198,12 @@ int main(int argc, char** argv) {
               {"loads only U=4", axpy_loads<4>},
               {"quad U=8 nt", axpy_quad<8, true>}, {"quad f32-round U=8", axpy_quad_f32<8>}, {"loads only U=8", axpy_loads<8>},
               {"loads only U=16", axpy_loads<16>}};
+    if (argc > 5) {  // calibration of the byte counters: ONE launch of the kernel k2_own runs, reading W x nl x reps x 256 bytes
+        axpy_quad<4, false><<<W, 1024>>>(J, n, lists, nl, reps, out);
+        CHECK(hipDeviceSynchronize());
+        printf("calibration launch: %.0f bytes of row segments\n", (double)W * nl * reps * 256.0);
+        return 0;
+    }
     for (auto& v : vs) {
         v.k<<<W, 1024>>>(J, n, lists, nl, 2, out);
         CHECK(hipDeviceSynchronize());

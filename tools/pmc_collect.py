@@ -82,7 +82,8 @@ def main():
     text = "\n".join(lines) + "\n"
     print(text)
     os.makedirs("gpurun_out/pmc_summaries", exist_ok=True)
-    open(f"gpurun_out/pmc_summaries/r02_pmc_{tag}.txt", "w").write(text)
+    rnd = os.environ.get("PMC_ROUND", "r03")
+    open(f"gpurun_out/pmc_summaries/{rnd}_pmc_{tag}.txt", "w").write(text)
     open(f"gpurun_out/pmc_summaries/{tag}.json", "w").write(json.dumps(entry, indent=1))
 
 
