@@ -327,13 +327,17 @@ def time_sparse_chain(hip, ctx, counters, n=1 << 24):
     ms = ctx.timer_end() / 50
     _, m = g.energy()
     g.close()
-    alg = 17 + 13 * 2  # bytes per update: row extent 8 + bias 8 + state write 1, per neighbour column 4 + coupling 8 + bit 1
+    # a uniform chain's colour classes are REGULAR (csrc/sparse.hip: k5_stencil): no CSR streams, per update two neighbour bits read and
+    # one byte written = 3 B (the general CSR kernel moved 17 + 13 deg = 43 B per update)
+    alg = 3
     gbs = alg * n / (ms * 1e-3) / 1e9
     return {"sites": n, "ms_per_sweep": ms, "spin_updates_per_s": n / (ms * 1e-3),
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "traffic": counters.get("k5_color_chain_2p24", {}).get("hbm_bytes"),
-                         "note": "algorithmic 17 + 13 deg bytes per update (CSR gather kernel, deg = 2) = 361 MB per launch of one colour "
-                                 "class (2^23 sites); traffic: PMC bytes per such launch (upper estimate, see profiles/counters.json)"},
+                         "traffic": None,
+                         "note": "regular colour classes (k5_stencil): algorithmic 3 B per update (2 neighbour bits + 1 write) = 25 MB per launch "
+                                 "of one colour class (2^23 sites), so the kernel is bound by instruction issue (one Philox block per update) and "
+                                 "by its two launches per sweep, not by HBM; the round-2 CSR kernel moved 43 B per update (0.52 of the roofline at "
+                                 "9.6e10 updates/s); traffic: not collected for this kernel"},
             "M": m / n}
 
 

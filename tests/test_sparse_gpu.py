@@ -152,3 +152,44 @@ def test_million_site_chain_nearest_neighbour_correlation():
     assert abs(c.magnetization(s)) < 0.01
     gs, e = c.find_ground_state(n_steps=60)
     assert e / n < -0.9                              # annealed towards the ferromagnetic ground state (domains remain)
+
+
+def _regular(shape, n):
+    from tsu.graph import canonical_csr
+    if shape in ("chain", "chain_edge_bias"):
+        A = _chain(n, 0.8)
+    elif shape == "ring":
+        A = canonical_csr(sp.diags([np.full(n - 1, 0.8), np.full(n - 1, 0.8), [0.8], [0.8]], [1, -1, n - 1, -(n - 1)]))
+    else:  # a two-leg ladder of n / 2 rungs: site 2 i + r, legs along i, rungs between r = 0 and r = 1 (degree 3 inside)
+        L = n // 2
+        i = np.arange(L - 1)
+        rows = np.concatenate([2 * i, 2 * i + 1, 2 * np.arange(L)])
+        cols = np.concatenate([2 * i + 2, 2 * i + 3, 2 * np.arange(L) + 1])
+        B = sp.coo_matrix((np.full(rows.size, -0.6), (rows, cols)), shape=(n, n))
+        A = canonical_csr(B + B.T)
+    bias = np.full(n, 0.3)
+    if shape == "chain_edge_bias":  # the bit bias of an open chain (tsu/models/ising.py:148): degree-dependent at the two ends
+        bias = np.full(n, -1.6)
+        bias[0] = bias[-1] = -0.8
+    return A, bias
+
+
+@pytest.mark.parametrize("shape,n", [("chain", 300001), ("chain_edge_bias", 70001), ("ring", 100000), ("ladder", 80000)])
+def test_regular_colour_classes_on_the_stencil_kernel_match_the_oracle(shape, n):
+    """Uniform couplings and bias, neighbours at fixed position offsets (`IsingChain`, rings, ladders): the colour classes run
+    k5_stencil (no CSR streams, integer thresholds from the count of set neighbours) with their few end rows on the generic
+    kernel -- the same bits as the oracle's sequential loop on the CSR rows."""
+    from tsu import _hip
+    from tsu.graph import color_graph
+    A, bias = _regular(shape, n)
+    st = np.random.default_rng(n).integers(0, 2, size=n).astype(np.int8)
+    offsets, order = color_graph(A)
+    g = _hip.SparseSystem(A.indptr, A.indices, A.data, bias, offsets, order)
+    g.set_state(st)
+    g.sweep(1.1, 4, seed=17, sweep0=3)
+    want = ora.sparse_sweep_philox(st, A.indptr, A.indices, A.data, bias, 1.1, 4, 17, sweep0=3, order=order)
+    np.testing.assert_array_equal(g.get_state(), want)
+    g.sweep(0.4, 2, seed=17, sweep0=7)  # another temperature: the thresholds are those of the call
+    want = ora.sparse_sweep_philox(want, A.indptr, A.indices, A.data, bias, 0.4, 2, 17, sweep0=7, order=order)
+    np.testing.assert_array_equal(g.get_state(), want)
+    g.close()

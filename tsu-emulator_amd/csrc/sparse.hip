@@ -29,10 +29,79 @@ struct tsu_sparse {
     size_t samples_cap;
     double* d_red;      // [energy, sum_spins as double pair] reduction target
     int64_t nnz;
+    // regular colour classes (k5_stencil): see K5Stencil
+    std::vector<struct K5Stencil> stencil;  // one per colour; deg < 0: the class is not regular
+    unsigned long long* d_thr;              // [n_colors][K5_MAX_DEG + 1] acceptance thresholds of the current call
+};
+
+// A REGULAR colour class (chains, rings, ladders ...: `IsingChain`, tsu/models/ising.py:265-286): apart from at most K5_EDGE rows at
+// either end of its position range, every row has the same degree, the same coupling on every edge, the same bias, neighbours at
+// fixed position offsets and a site number that is affine in the position.  Such a class needs no CSR streams at all: per update it
+// reads its neighbours' bits (deg bytes, contiguous across the lanes) and writes one byte -- ~3 B instead of 43 for a chain -- and
+// the field takes deg + 1 values only, so acceptance is one integer compare of the uniform's 53 bits with a threshold computed (on
+// the device, with the generic kernel's own expressions) from the number of set neighbours.  The end rows run on the generic kernel.
+#define K5_MAX_DEG 4
+#define K5_EDGE 64
+struct K5Stencil {
+    int deg;            // -1: not regular
+    int pb, pe;         // position range of the class
+    int lo, hi;         // rows [pb, pb + lo) and [pe - hi, pe) are irregular (generic kernel)
+    int off[K5_MAX_DEG];
+    double Jv, bias;
+    int site0, site_stride;  // site of position p = site0 + site_stride * (p - pb - lo)
 };
 
 namespace {
 
+// thresholds of a regular class: thr[k] = ceil(p_k 2^53), p_k = sigmoid((k-fold sum of Jv + bias) / T) -- the field the generic kernel
+// computes for a row with k set neighbours (it adds val * bit edge by edge: zeros change nothing), so that `u < p` for the 53-bit
+// uniform u = m / 2^53 is `m < thr[k]`
+__global__ void k5_thresholds(int deg, double Jv, double bias, double T, unsigned long long* __restrict__ thr) {
+    const int k = threadIdx.x;
+    if (k > K5_MAX_DEG) return;
+    if (k > deg) {
+        thr[k] = 0ull;
+        return;
+    }
+    double F = 0.0;
+    for (int i = 0; i < k; ++i) F += Jv * 1.0;
+    F += bias;
+    const double p = sigmoid_clamped(F / T);
+    thr[k] = p >= 1.0 ? (1ull << 53) : (unsigned long long)ceil(ldexp(p, 53));
+}
+
+// one launch per colour class: the regular rows by count and threshold, the few irregular end rows (first and last waves only) by the
+// generic expression on their CSR rows
+__global__ __launch_bounds__(256) void k5_stencil(int8_t* __restrict__ state, K5Stencil S, const unsigned long long* __restrict__ thr,
+                                                  const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col, const double* __restrict__ val,
+                                                  const double* __restrict__ bias, const int32_t* __restrict__ site_of, double T, uint32_t sweep,
+                                                  uint32_t tag, uint32_t k0, uint32_t k1) {
+    const int p = S.pb + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (p >= S.pe) return;
+    if (p < S.pb + S.lo || p >= S.pe - S.hi) {
+        double F = 0.0;
+        for (int64_t e = row_ptr[p]; e < row_ptr[p + 1]; ++e) F += val[e] * (double)state[col[e]];
+        F += bias[p];
+        const double u = dense_uniform((uint32_t)site_of[p], sweep, tag, k0, k1);
+        state[p] = (u < sigmoid_clamped(F / T)) ? 1 : 0;
+        return;
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < K5_MAX_DEG; ++i)
+        if (i < S.deg) cnt += state[p + S.off[i]];
+    const uint32_t site = (uint32_t)(S.site0 + S.site_stride * (p - S.pb - S.lo));
+    const u32x4 w = tsu_philox(site >> 1, 0u, sweep, tag, k0, k1);  // dense_uniform's block and words (dense.h)
+    const uint32_t a = ((site & 1) ? w.z : w.x) >> 5, b = ((site & 1) ? w.w : w.y) >> 6;
+    const unsigned long long m = ((unsigned long long)a << 26) | b;
+    // (the five thresholds sit at uniform addresses: scalar loads issued at the top, selected by the count -- no dependent vector load)
+    unsigned long long t = thr[0];
+#pragma unroll
+    for (int i = 1; i <= K5_MAX_DEG; ++i) t = cnt == i ? thr[i] : t;
+    state[p] = m < t ? 1 : 0;
+}
+
+// the generic update for an explicit list of rows [p_begin, p_end) -- the irregular end rows of a regular class
 __global__ __launch_bounds__(256) void k5_color(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
                                                 const double* __restrict__ val, const double* __restrict__ bias,
                                                 const int32_t* __restrict__ site_of, int8_t* __restrict__ state, int p_begin,
@@ -127,10 +196,21 @@ int run_sweeps(tsu_sparse* g, double T, int n_sweeps, uint64_t seed, uint32_t sw
         TSU_HIP_TRY(ctx, hipGetLastError());
         return TSU_OK;
     }
+    for (int c = 0; c < g->n_colors; ++c) {  // thresholds of the regular classes at this call's temperature
+        const K5Stencil& S = g->stencil[(size_t)c];
+        if (S.deg > 0) hipLaunchKernelGGL(k5_thresholds, dim3(1), dim3(64), 0, ctx->stream, S.deg, S.Jv, S.bias, T, g->d_thr + (size_t)c * (K5_MAX_DEG + 1));
+    }
     for (int s = 0; s < n_sweeps; ++s) {
         for (int c = 0; c < g->n_colors; ++c) {
             const int pb = g->color_off[c], pe = g->color_off[c + 1];
             if (pe <= pb) continue;
+            const K5Stencil& S = g->stencil[(size_t)c];
+            if (S.deg > 0) {
+                hipLaunchKernelGGL(k5_stencil, dim3((unsigned)((pe - pb + 255) / 256)), dim3(256), 0, ctx->stream, g->state, S,
+                                   g->d_thr + (size_t)c * (K5_MAX_DEG + 1), g->row_ptr, g->col, g->val, g->bias, g->site_of, T, sweep0 + (uint32_t)s, tag,
+                                   k0, k1);
+                continue;
+            }
             hipLaunchKernelGGL(k5_color, dim3((unsigned)((pe - pb + 255) / 256)), dim3(256), 0, ctx->stream, g->row_ptr, g->col, g->val, g->bias,
                                g->site_of, g->state, pb, pe, T, sweep0 + (uint32_t)s, tag, k0, k1);
         }
@@ -144,7 +224,7 @@ int run_sweeps(tsu_sparse* g, double T, int n_sweeps, uint64_t seed, uint32_t sw
 }
 
 void free_all(tsu_sparse* g) {
-    void* ptrs[] = {g->row_ptr, g->col, g->val, g->bias, g->site_of, g->pos_of, g->state, g->staging, g->samples, g->d_red};
+    void* ptrs[] = {g->row_ptr, g->col, g->val, g->bias, g->site_of, g->pos_of, g->state, g->staging, g->samples, g->d_red, g->d_thr};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete g;
@@ -204,6 +284,47 @@ int tsu_sparse_create(tsu_ctx* ctx, int n, const int64_t* row_ptr, const int32_t
     g->n = n;
     g->n_colors = n_colors;
     g->nnz = nnz;
+    g->d_thr = nullptr;
+    // regular colour classes: the pattern of the class's middle row must hold for every row but at most K5_EDGE at either end
+    static const bool use_stencil = !(getenv("TSU_K5_STENCIL") && atoi(getenv("TSU_K5_STENCIL")) == 0);
+    g->stencil.assign((size_t)n_colors, K5Stencil());
+    for (int c = 0; c < n_colors; ++c) {
+        K5Stencil& S = g->stencil[(size_t)c];
+        S.deg = -1;
+        const int pb = color_offsets[c], pe = color_offsets[c + 1];
+        if (!use_stencil || pe - pb < 4 * K5_EDGE + 2) continue;
+        const int pm = pb + (pe - pb) / 2;
+        const int deg = (int)(rp[(size_t)pm + 1] - rp[(size_t)pm]);
+        if (deg < 1 || deg > K5_MAX_DEG) continue;
+        K5Stencil T;
+        T.deg = deg;
+        T.pb = pb;
+        T.pe = pe;
+        T.Jv = vp[(size_t)rp[(size_t)pm]];
+        T.bias = bp[(size_t)pm];
+        for (int i = 0; i < K5_MAX_DEG; ++i) T.off[i] = i < deg ? cp[(size_t)rp[(size_t)pm] + i] - pm : 0;
+        T.site_stride = order[pm + 1] - order[pm];
+        auto fits = [&](int p) {
+            if (rp[(size_t)p + 1] - rp[(size_t)p] != deg || bp[(size_t)p] != T.bias) return false;
+            if ((long long)order[p] != (long long)order[pm] + (long long)T.site_stride * (p - pm)) return false;
+            for (int i = 0; i < deg; ++i) {
+                const int64_t e = rp[(size_t)p] + i;
+                if (vp[(size_t)e] != T.Jv || cp[(size_t)e] - p != T.off[i] || cp[(size_t)e] == p) return false;  // (no self-loops: the row's own bit is rewritten)
+            }
+            return true;
+        };
+        int lo = 0, hi = 0;
+        while (lo <= K5_EDGE && !fits(pb + lo)) ++lo;
+        while (hi <= K5_EDGE && !fits(pe - 1 - hi)) ++hi;
+        if (lo > K5_EDGE || hi > K5_EDGE) continue;
+        bool ok = true;
+        for (int p = pb + lo; p < pe - hi && ok; ++p) ok = fits(p);
+        if (!ok) continue;
+        T.lo = lo;
+        T.hi = hi;
+        T.site0 = order[pb + lo];
+        S = T;
+    }
     g->color_off.assign(color_offsets, color_offsets + n_colors + 1);
     hipError_t e = hipSuccess;
     auto up = [&](void** dst, const void* src, size_t bytes) {
@@ -225,6 +346,7 @@ int tsu_sparse_create(tsu_ctx* ctx, int n, const int64_t* row_ptr, const int32_t
     if (e == hipSuccess) e = hipMemsetAsync(g->state, 0, (size_t)n, ctx->stream);
     if (e == hipSuccess) e = hipMalloc((void**)&g->staging, (size_t)n);
     if (e == hipSuccess) e = hipMalloc((void**)&g->d_red, 2 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&g->d_thr, (size_t)n_colors * (K5_MAX_DEG + 1) * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the host vectors go out of scope
     if (e != hipSuccess) {
         free_all(g);
