@@ -388,35 +388,40 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
     // group g_lo + k, ascending; with write_back the old masks become the new ones.  s_nl = entries, s_nle = entries up to and
     // including this workgroup's own groups (natural order: later sites never enter a correction).
     auto build_list = [&](const unsigned long long* newp, int sn, unsigned long long* oldp, int so, int g_lo, int np, bool write_back) {
-        int base = 0;
+        // lane l takes the groups [l gpl, (l + 1) gpl): one prefix scan whatever np is, entries in ascending site order
+        const int gpl = (np + 63) >> 6;
+        const int kb = lane * gpl, ke = kb + gpl < np ? kb + gpl : np;
+        int pc = 0;
+        for (int k = kb; k < ke; ++k) {
+            unsigned long long un = 0ull;
+#pragma unroll
+            for (int rho = 0; rho < R; ++rho) un |= newp[rho * sn + k] ^ (oldp ? oldp[rho * so + k] : 0ull);
+            pc += __popcll(un);
+        }
+        int off = pc;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const int v = __shfl_up(off, dd, 64);
+            if (lane >= dd) off += v;
+        }
+        const int total = __shfl(off, 63, 64);
+        off -= pc;
         if (lane == 0) {
             s_nle = 0;
             s_nlo = 0;
         }
-        for (int k0 = 0; k0 < np; k0 += 64) {
-            const int k = k0 + lane;
-            const bool okk = k < np;
+        for (int k = kb; k < ke; ++k) {
             unsigned long long nw[R], tg[R], un = 0ull;
 #pragma unroll
             for (int rho = 0; rho < R; ++rho) {
-                nw[rho] = okk ? newp[rho * sn + k] : 0ull;
-                const unsigned long long ol = (okk && oldp) ? oldp[rho * so + k] : 0ull;
-                tg[rho] = nw[rho] ^ ol;
+                nw[rho] = newp[rho * sn + k];
+                tg[rho] = nw[rho] ^ (oldp ? oldp[rho * so + k] : 0ull);
                 un |= tg[rho];
-                if (write_back && okk) oldp[rho * so + k] = nw[rho];
+                if (write_back) oldp[rho * so + k] = nw[rho];
             }
-            const int pc = __popcll(un);
-            int off = pc;
-#pragma unroll
-            for (int dd = 1; dd < 64; dd <<= 1) {
-                const int v = __shfl_up(off, dd, 64);
-                if (lane >= dd) off += v;
-            }
-            const int total = __shfl(off, 63, 64);
-            off = base + off - pc;
             const int g = g_lo + k;
             const int sbase = 64 * g;
-            if (okk && g == w * M) s_nlo = off;
+            if (g == w * M) s_nlo = off;
             while (un) {
                 const int b = __ffsll((long long)un) - 1;
                 un &= un - 1ull;
@@ -426,10 +431,9 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                     if ((tg[rho] >> b) & 1ull) code |= (1u | (((nw[rho] >> b) & 1ull) ? 0u : 2u)) << (2 * rho);
                 lst[off++] = (uint32_t)(sbase + b) | (code << 16);
             }
-            if (okk && g == w * M + M - 1) s_nle = off;
-            base += total;
+            if (g == w * M + M - 1) s_nle = off;
         }
-        if (lane == 0) s_nl = base;
+        if (lane == 0) s_nl = total;
     };
 
     // (natural order) the workgroups that decide the NEXT superblock have its predecessor's flips already (they followed its generations)
