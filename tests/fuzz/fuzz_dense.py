@@ -16,6 +16,9 @@ for case in range(int(os.environ.get("FUZZ_CASES", "30"))):
         n = 4 * random.randint(256, 2300)
     if os.environ.get("FUZZ_PIPE_LOW"):  # the pipeline kernel just above the one-workgroup kernel's range: a single short superblock
         n = 4 * random.randint(113, 300)
+    own = bool(os.environ.get("FUZZ_OWN"))  # the owner-computes kernel: N a multiple of 4 from 2048; natural / caller's order / replicas
+    if own:
+        n = 4 * random.randint(512, 2400)
     f32 = random.random() < 0.5
     sym = random.random() < 0.7
     T = random.choice([0.1, 0.5, 1.0, 3.0])
@@ -24,7 +27,7 @@ for case in range(int(os.environ.get("FUZZ_CASES", "30"))):
     J = rng.standard_normal((n, n)) / max(1.0, np.sqrt(n)) * random.choice([0.3, 1.0, 3.0])
     if sym:
         J = (J + J.T) / 2
-    if (os.environ.get("FUZZ_SMALL") or os.environ.get("FUZZ_MID") or os.environ.get("FUZZ_PIPE") or os.environ.get("FUZZ_PIPE_LOW")) and random.random() < 0.3:  # ferromagnet / antiferromagnet: long dependency chains
+    if (own or os.environ.get("FUZZ_SMALL") or os.environ.get("FUZZ_MID") or os.environ.get("FUZZ_PIPE") or os.environ.get("FUZZ_PIPE_LOW")) and random.random() < 0.3:  # ferromagnet / antiferromagnet: long dependency chains
         J = np.full((n, n), random.choice([1.0, -1.0, 0.25]) * random.choice([1.0, 1.0 / max(1, n)]))
         np.fill_diagonal(J, 0.0)
     if f32:
@@ -34,9 +37,28 @@ for case in range(int(os.environ.get("FUZZ_CASES", "30"))):
     d = _hip.DenseSystem(J, b, _hip.DTYPE_F32 if f32 else _hip.DTYPE_F64)
     d.set_state(st)
     seed, s0 = random.getrandbits(40), random.randrange(1000)
-    d.sweep(T, sweeps, seed=seed, sweep0=s0)
-    ok = (d.get_state() == ora.dense_sweep_philox(st, J, b, T, sweeps, seed, sweep0=s0)).all()
-    print(("ok  " if ok else "FAIL"), "n", n, "f32" if f32 else "f64", "sym" if sym else "asym", "T", T, "sweeps", sweeps, flush=True)
+    what = random.choice(["natural", "natural", "order", "replicas"]) if own else "natural"
+    if own:
+        sweeps = min(sweeps, 3)
+        os.environ["TSU_K2_OWN_SB"] = str(random.choice([1024, 2048, 4096, 8192]))
+        os.environ["TSU_K2_OWN_M"] = str(random.choice([1, 1, 2, 4])) if what != "replicas" else "1"
+    if what == "natural":
+        d.sweep(T, sweeps, seed=seed, sweep0=s0)
+        ok = (d.get_state() == ora.dense_sweep_philox(st, J, b, T, sweeps, seed, sweep0=s0)).all()
+    elif what == "order":
+        order = np.array([rng.permutation(n) for _ in range(sweeps)])
+        d.sweep(T, sweeps, seed=seed, sweep0=s0, order=order)
+        ok = (d.get_state() == ora.dense_sweep_philox(st, J, b, T, sweeps, seed, sweep0=s0, order=order)).all()
+    else:
+        R = random.randint(2, 9)
+        sts = rng.integers(0, 2, size=(R, n)).astype(np.int8)
+        temps = [T * (1 + 0.2 * r) for r in range(R)]
+        out = d.sweep_replicas(sts, temps, sweeps, [seed + r for r in range(R)], [s0 + r for r in range(R)], replicas=list(range(R)))
+        ok = all((out[r] == ora.dense_sweep_philox(sts[r], J, b, temps[r], sweeps, seed + r, sweep0=s0 + r, replica=r)).all() for r in range(R))
+    if own and sum(d.launch_counts()) == 0:
+        print("(not on a one-launch kernel)", end=" ")
+    print(("ok  " if ok else "FAIL"), what, "n", n, "f32" if f32 else "f64", "sym" if sym else "asym", "T", T, "sweeps", sweeps,
+          os.environ.get("TSU_K2_OWN_SB", ""), os.environ.get("TSU_K2_OWN_M", ""), d.launch_counts(), flush=True)
     d.close()
     if not ok:
         sys.exit(1)
