@@ -187,6 +187,8 @@ static __device__ __forceinline__ void own_axpy(const TJ* __restrict__ JT, int n
 #pragma unroll
             for (int m = 0; m < 4; ++m) acc[a][m] = 0.0;
         if (MODE == 1) {
+            // (a short list in ONE masked pass: the unmasked and the masked range would be two dependent round trips to memory)
+            if (nl <= OWN_WAVES * 4 * (4 / M)) nlo = 0;
             if (r0 == 0) {
                 own_axpy_range<TJ, M, 0, RG, 1, false>(JT, n, lst, 0, nlo, col0, myrow, pos, mypos, acc, lane, wv);
                 own_axpy_range<TJ, M, 0, RG, 1, true>(JT, n, lst, nlo, nl, col0, myrow, pos, mypos, acc, lane, wv);
