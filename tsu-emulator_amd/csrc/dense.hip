@@ -920,17 +920,6 @@ int tsu_dense_sweep(tsu_dense* d, double T, int n_sweeps, const int64_t* order, 
     if (n_sweeps == 0) return TSU_OK;
     size_t cnt = (size_t)n_sweeps * d->n;
     if (order) {
-        // every sweep must visit every site exactly once (np.random.permutation, gibbs.py:157): the sweep reads the
-        // frozen current state for "old" bits, which is only right for a site's first visit
-        std::vector<char> seen((size_t)d->n);
-        for (int sw = 0; sw < n_sweeps; ++sw) {
-            std::fill(seen.begin(), seen.end(), 0);
-            for (int i = 0; i < d->n; ++i) {
-                long long v = order[(size_t)sw * d->n + i];
-                TSU_REQUIRE(ctx, v >= 0 && v < d->n && !seen[(size_t)v], "dense_sweep: order row %d is not a permutation of 0..%d", sw, d->n - 1);
-                seen[(size_t)v] = 1;
-            }
-        }
         if (d->order_cap < cnt) {
             if (d->order) (void)hipFree(d->order);
             d->order = nullptr;
@@ -938,7 +927,29 @@ int tsu_dense_sweep(tsu_dense* d, double T, int n_sweeps, const int64_t* order, 
             TSU_HIP_TRY(ctx, hipMalloc(&d->order, cnt * 8));
             d->order_cap = cnt;
         }
+        // (the upload runs while the host checks the rows; nothing reads the device copy before the synchronisation below)
         TSU_HIP_TRY(ctx, hipMemcpyAsync(d->order, order, cnt * 8, hipMemcpyHostToDevice, ctx->stream));
+        // every sweep must visit every site exactly once (np.random.permutation, gibbs.py:157): the sweep reads the
+        // frozen current state for "old" bits, which is only right for a site's first visit
+        std::vector<int> seen((size_t)d->n, -1);  // the row that saw the site last: one pass, no clearing per row
+        bool ok = true;
+        int bad_row = -1;
+        for (int sw = 0; sw < n_sweeps && ok; ++sw) {
+            const int64_t* row = order + (size_t)sw * d->n;
+            for (int i = 0; i < d->n; ++i) {
+                const long long v = row[i];
+                if (v < 0 || v >= d->n || seen[(size_t)v] == sw) {
+                    ok = false;
+                    bad_row = sw;
+                    break;
+                }
+                seen[(size_t)v] = sw;
+            }
+        }
+        if (!ok) {
+            (void)hipStreamSynchronize(ctx->stream);
+            return tsu_fail(ctx, TSU_E_INVALID, "dense_sweep: order row %d is not a permutation of 0..%d", bad_row, d->n - 1);
+        }
     }
     if (replay_uniforms) {
         if (d->uni_cap < cnt) {

@@ -125,7 +125,6 @@ static __device__ __forceinline__ void own_axpy_range(const TJ* __restrict__ JT,
     if (wv >= nb) return;
     auto consume = [&](const OwnQuad<TJ>& xq, uint32_t ev) {
         const int j = (int)(ev & 0xFFFFu);
-        const uint32_t code = ev >> 16;
         double v[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) v[m] = xq.get(m);
@@ -752,17 +751,28 @@ int tsu_dense_own_run(tsu_dense* d, int R_real, const OwnRep* reps, int8_t* stat
     if (!M || (R > 1 && M != 1) || n % 4) return TSU_OK;  // (rows travel as quads)
     const int RW = 64 * M, W = (n + RW - 1) / RW, G = W * M;
     if (W < 2) return TSU_OK;
-    int sb = sb_env > 0 ? sb_env : 4096;
-    if (sb < RW) sb = RW;
-    if (sb > 8192) sb = 8192;
-    int sbw = sb / RW;
-    if (sbw > W) sbw = W;
-    const int lmax = sbw * RW;
-    const int nsb = ord ? (n + sbw * RW - 1) / (sbw * RW) : (W + sbw - 1) / sbw;
+    // superblock: 4096 positions in natural order; a caller's order pays more per generation (every workgroup polls every group and
+    // follows every toggle), so fewer, longer fixed points win there: the largest of 16384 / 8192 / 4096 whose toggle list fits the LDS
+    // (n = 16384: 0.429 / 0.349 / 0.317 / 0.293 ms per sweep at 2048 / 4096 / 8192 / 16384)
+    int sb = 0, sbw = 0, lmax = 0, nsb = 0, NP = 0;
+    const int NA = ord ? 2 : R;
+    size_t lds_bytes = 0;
+    const int cands[3] = {16384, 8192, 4096};
+    for (int ci = sb_env > 0 ? 2 : (ord ? 0 : 2); ci < 3; ++ci) {
+        sb = sb_env > 0 ? sb_env : cands[ci];
+        if (sb < RW) sb = RW;
+        if (sb > 16384) sb = 16384;
+        sbw = sb / RW;
+        if (sbw > W) sbw = W;
+        lmax = sbw * RW;
+        nsb = ord ? (n + sbw * RW - 1) / (sbw * RW) : (W + sbw - 1) / sbw;
+        NP = ord ? G : sbw * M;
+        lds_bytes = ((size_t)8 * (R * G + 2 * R * NP) + (size_t)8 * OWN_WAVES * NA * M * 64 + (size_t)4 * lmax + (size_t)8 * (3 * R + 1) * M * 64 +
+                     (ord ? (size_t)2 * n : 0) + 15) / 16 * 16;
+        if (lds_bytes <= 150 * 1024) break;
+    }
     if (!ord && nsb > OWN_RING) return TSU_OK;
     if ((long long)n_sweeps * nsb >= (long long)(0xFFFFFFFFu / OWN_TAG_SPAN) - 2) return TSU_OK;  // generation tags are 32 bits
-    const int NP = ord ? G : sbw * M, NA = ord ? 2 : R;
-    const size_t lds_bytes = ((size_t)8 * (R * G + 2 * R * NP) + (size_t)8 * OWN_WAVES * NA * M * 64 + (size_t)4 * lmax + (size_t)8 * (3 * R + 1) * M * 64 + (ord ? (size_t)2 * n : 0) + 15) / 16 * 16;
     if (lds_bytes > 150 * 1024) return TSU_OK;
     own_kern kern = d->dtype == TSU_DTYPE_F64 ? own_pick<double>(M, R, ord) : own_pick<float>(M, R, ord);
     if (!kern) return TSU_OK;
