@@ -204,3 +204,45 @@ def test_config3_16384_properties_over_a_long_call():
     d.sweep(1.0, 2, seed=9, sweep0=0)
     np.testing.assert_array_equal(d.get_state(), ora.dense_sweep_philox(s0, J.astype(np.float64), None, 1.0, 2, 9, sweep0=0))
     d.close()
+
+
+def test_a_run_that_gives_up_half_way_is_redone_on_the_other_paths():
+    """k2_own's waits are bounded: a lost peer (a GPU shared with another long-running kernel) makes it give up with the state half
+    updated.  The callers then restore the state of the call's start and the other paths redo the call -- same result.  Forced here
+    by TSU_K2_OWN_TEST_FAIL (the kernel stops at a given superblock as if a wait had expired)."""
+    n = 8192
+    J, b, s0 = _system(n, 19, False)
+    J64 = J.astype(np.float64)
+    with _env(TSU_K2_OWN_TEST_FAIL=5):
+        d = _dense(J, b, False)
+        d.set_state(s0)
+        d.sweep(1.0, 3, seed=7, sweep0=2)  # natural order: 2 superblocks x 3 sweeps, gives up in the last one -> the pipeline
+        assert d.launch_counts() == (0, 1)
+        np.testing.assert_array_equal(d.get_state(), ora.dense_sweep_philox(s0, J64, b, 1.0, 3, 7, sweep0=2))
+        d.sweep(0.8, 1, seed=7, sweep0=5)  # later calls skip k2_own
+        assert d.launch_counts() == (0, 2)
+        d.close()
+        # a recorded run (sample_boltzmann in one launch)
+        d = _dense(J, b, False)
+        d.set_state(s0)
+        got = d.sample(0.9, 1, 1, 3, seed=3, sweep0=0)
+        want = ora.dense_sweep_philox(s0, J64, b, 0.9, 1, 3, sweep0=0)
+        for k in range(3):
+            want = ora.dense_sweep_philox(want, J64, b, 0.9, 1, 3, sweep0=1 + k)
+            np.testing.assert_array_equal(got[k], want, err_msg=f"sample {k}")
+        d.close()
+    n = 2304
+    J, b, s0 = _system(n, 23, False)
+    J64 = J.astype(np.float64)
+    order = np.array([np.random.default_rng(1).permutation(n) for _ in range(2)])
+    with _env(TSU_K2_OWN_TEST_FAIL=1):
+        d = _dense(J, b, False)
+        d.set_state(s0)
+        d.sweep(0.9, 2, seed=3, sweep0=5, order=order)  # a caller's order: the block-by-block path redoes it
+        assert d.launch_counts() == (0, 0)
+        np.testing.assert_array_equal(d.get_state(), ora.dense_sweep_philox(s0, J64, b, 0.9, 2, 3, sweep0=5, order=order))
+        sts = np.array([np.random.default_rng(r).integers(0, 2, size=n) for r in range(3)], dtype=np.int8)
+        out = d.sweep_replicas(sts, [1.0, 0.7, 1.4], 2, [1, 2, 3], [0, 0, 0], replicas=[0, 1, 2])  # replicas: one after the other
+        for r in range(3):
+            np.testing.assert_array_equal(out[r], ora.dense_sweep_philox(sts[r], J64, b, [1.0, 0.7, 1.4][r], 2, 1 + r, sweep0=0, replica=r))
+        d.close()

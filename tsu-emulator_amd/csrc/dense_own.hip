@@ -56,6 +56,7 @@ struct OwnParams {
     int sbw;                     // workgroups per superblock (natural order); positions per superblock = sbw * 64 M
     int lmax;                    // toggle-list capacity (entries) = positions per superblock
     int rec_from, rec_every, resume, persist, refresh_off;
+    int fail_at;                 // (tests) give up at this superblock number as if a wait had expired; < 0: never
     OwnRep rep[OWN_MAX_R];
 };
 
@@ -514,6 +515,10 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
             }
         }
         for (int sb = 0; sb < nsb; ++sb, ++seq) {
+            if (P.fail_at >= 0 && (int)seq == P.fail_at) {  // (tests of the callers' recovery: the state is half updated here)
+                if (threadIdx.x == 0) st(&P.bar[BAR_ERR], 1u);
+                return;
+            }
             const bool active = ORD || w / P.sbw == sb;
             const int g_lo = ORD ? 0 : sb * P.sbw * M;
             const int np = ORD ? G : (G - g_lo < NP ? G - g_lo : NP);
@@ -816,6 +821,7 @@ int tsu_dense_own_run(tsu_dense* d, int R_real, const OwnRep* reps, int8_t* stat
     P.lmax = lmax;
     P.rec_from = rec_from;
     P.rec_every = rec_every > 0 ? rec_every : 1;
+    P.fail_at = own_env("TSU_K2_OWN_TEST_FAIL", -1);
     for (int r = 0; r < R; ++r) P.rep[r] = reps[r < R_real ? r : 0];  // (padding replicas repeat replica 0 on its own state copy: see the caller)
     static const int keep_fields = own_env("TSU_K2_KEEP_FIELDS", 1);
     const bool single = R_real == 1 && allow_persist;
