@@ -32,6 +32,7 @@
                                 // OWN_RING superblocks, checked by the host)
 #define OWN_TAG_SPAN 16384u     // generation g of superblock number q carries tag q * SPAN + g + 1 (0 = never written)
 #define OWN_MAX_R 8
+#define OWN_SOLO_MAX 32           // toggle-list entries (before the workgroup's last row) a deciding wave gathers by itself
 #ifndef OWN_REP_QUAD
 #define OWN_REP_QUAD 0          // replicas: 0 = one row per lane, scalar multipliers (own_axpy_rep); 1 = the quad layout in groups of four replicas
 #endif
@@ -57,6 +58,7 @@ struct OwnParams {
     int lmax;                    // toggle-list capacity (entries) = positions per superblock
     int rec_from, rec_every, resume, persist, refresh_off;
     int fail_at;                 // (tests) give up at this superblock number as if a wait had expired; < 0: never
+    int solo;                    // natural order, one replica, 64 rows per workgroup: short generations by the deciding wave alone
     OwnRep rep[OWN_MAX_R];
 };
 
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
     constexpr int ND = R > 1 ? R : M;    // deciding waves: one per 64 rows (M of them), or -- several replicas, M = 1 -- one per replica
     constexpr int PW = ND;               // the wave that polls and builds the lists (the first one that decides nothing)
     extern __shared__ unsigned long long own_lds[];
-    __shared__ int s_nl, s_nlo, s_nle, s_fail;
+    __shared__ int s_nl, s_nlo, s_nle, s_cmd, s_fail;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int w = (int)blockIdx.x, W = (int)gridDim.x, G = W * M;
     const int n = P.n;
@@ -545,7 +547,159 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                 int vnew = vcur;
                 unsigned gi = 0;
                 OWN_MARK(0);
-                while (true) {
+                // ---- SOLO generations (natural order, one replica, 64 rows per workgroup): wave 0 runs a generation from the decision to
+                // the next decision by itself -- publish, poll, toggle list, the row segments of a SHORT list (most generations move a
+                // handful of sites), the sum over its entry slots, the new correction -- with no workgroup barrier, no hand-over to a
+                // polling wave and no sixteen-wave reduction through LDS; the other fifteen waves wait at a barrier and are called in
+                // only for long lists (the first correction pass).  Commands through s_cmd: 1 = an axpy pass over lst, 2 = converged.
+                const bool solo = !ORD && R == 1 && M == 1 && P.solo;
+                if (solo && wv != 0) {
+                    while (true) {
+                        __syncthreads();  // (A) a command from wave 0
+                        if (s_cmd != 1) break;
+                        OWN_AXPY_GEN(s_nlo, s_nle);
+                        __syncthreads();  // (B) the partial sums are in red
+                    }
+                } else if (solo) {
+                    const int kme = w - g_lo;  // my group's index among the polled ones (lane k <-> group g_lo + k)
+                    double Cm = 0.0;  // (field and logit stay in LDS: registers are short here)
+                    while (true) {
+                        const unsigned tag = seq * OWN_TAG_SPAN + gi + 1u;
+                        unsigned long long* gbuf = P.gen + (size_t)(gi % OWN_NGEN) * G * 2;
+                        int v = vcur & 1;
+                        if (mine) {
+                            const double Tw = OWN_TW(0);
+                            v = own_decide(dF[OWN_AT(0)] + Cm, dL[OWN_AT(0)], Tw, 1.0 / Tw, (uint32_t)site, (uint32_t)dpos, OWN_UNI(0), P.rep[0].sweep0 + (uint32_t)sw,
+                                           P.rep[0].tag, P.rep[0].k0, P.rep[0].k1);
+                        }
+                        vnew = v;
+                        const unsigned long long mk = __ballot(v != 0);
+                        if (lane < 2) st(gbuf + (size_t)mygroup * 2 + lane, ((mk >> (32 * lane)) & 0xFFFFFFFFull) | ((unsigned long long)tag << 32));
+                        // poll: lane k reads group g_lo + k's granule pair until every pair carries this generation's tag
+                        unsigned long long nw = 0ull;
+                        {
+                            const bool okk = lane < np;
+                            const unsigned long long* pp = gbuf + (size_t)(g_lo + (okk ? lane : 0)) * 2;
+                            const long long t0 = wall_clock64();
+                            bool failed = false;
+                            for (unsigned spins = 0;; ++spins) {
+                                const unsigned long long lo = ld(pp), hi = ld(pp + 1);
+                                const bool all = !okk || ((unsigned)(lo >> 32) == tag && (unsigned)(hi >> 32) == tag);
+                                nw = (lo & 0xFFFFFFFFull) | (hi << 32);
+                                if (__ballot(!all) == 0ull) break;
+                                if ((spins & 63u) == 63u && (ld(&P.bar[BAR_ERR]) || wall_clock64() - t0 > CO_TIMEOUT)) {
+                                    st(&P.bar[BAR_ERR], 1u);
+                                    failed = true;
+                                    break;
+                                }
+                            }
+                            if (failed) {
+                                if (lane == 0) {
+                                    s_fail = 1;
+                                    s_cmd = 2;
+                                }
+                                __syncthreads();  // (A) releases the waiting waves
+                                return;
+                            }
+                        }
+                        OWN_MARK(gi == 0 ? 9 : 1);
+                        // toggle list (ascending sites: one group per lane, one prefix scan)
+                        const unsigned long long tg0 = lane < np ? nw ^ gm[lane] : 0ull;  // (gm: one group per lane, this wave's only)
+                        if (lane < np) gm[lane] = nw;
+                        const int pc = __popcll(tg0);
+                        int off = pc;
+#pragma unroll
+                        for (int dd = 1; dd < 64; dd <<= 1) {
+                            const int x = __shfl_up(off, dd, 64);
+                            if (lane >= dd) off += x;
+                        }
+                        const int nl = __shfl(off, 63, 64);
+                        off -= pc;
+                        const int nlo = __shfl(off, kme, 64), nle = __shfl(off + pc, kme, 64);
+                        if (timing) {
+                            tl[4] += 1;
+                            tl[5] += (unsigned long long)nl;
+                        }
+                        if (nl == 0) break;  // nobody's value changed: the fixed point
+                        {
+                            unsigned long long un = tg0;
+                            const int g = g_lo + lane;
+                            while (un) {
+                                const int b = __ffsll((long long)un) - 1;
+                                un &= un - 1ull;
+                                lst[off++] = (uint32_t)(64 * g + b) | ((1u | (((nw >> b) & 1ull) ? 0u : 2u)) << 16);
+                            }
+                        }
+                        if (nle <= OWN_SOLO_MAX) {
+                            // the short list by this wave alone: bundles of 4 entries, SU in flight per round, per-lane masks throughout
+                            __builtin_amdgcn_wave_barrier();
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the list is read back by other lanes of this wave)
+                            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+                            const int t = lane >> 4, nb = (nle + 3) >> 2;
+                            constexpr int SU = sizeof(TJ) == 4 ? 4 : 2;  // bundles in flight
+                            for (int b0 = 0; b0 < nb; b0 += SU) {
+                                OwnQuad<TJ> x[SU];
+                                uint32_t e[SU];
+#pragma unroll
+                                for (int u = 0; u < SU; ++u) {
+                                    const int k = (b0 + u) * 4 + t;
+                                    e[u] = k < nle ? lst[k] : 0u;
+                                }
+#pragma unroll
+                                for (int u = 0; u < SU; ++u)
+                                    if (b0 + u < nb) x[u].load(JT + (size_t)(e[u] & 0xFFFFu) * n + col0);
+#pragma unroll
+                                for (int u = 0; u < SU; ++u)
+                                    if (b0 + u < nb) {
+                                        const int j = (int)(e[u] & 0xFFFFu);
+                                        const double sg = (double)(((int)(e[u] << 14)) >> 30);
+#pragma unroll
+                                        for (int m = 0; m < 4; ++m) acc[m] += j < myrow + m ? sg * x[u].get(m) : 0.0;
+                                    }
+                            }
+#pragma unroll
+                            for (int m = 0; m < 4; ++m) {
+                                acc[m] += __shfl_xor(acc[m], 16, 64);
+                                acc[m] += __shfl_xor(acc[m], 32, 64);
+                            }
+                            // lanes 0..15 hold a quad of rows each: back to one row per lane through LDS (this wave only)
+                            if (lane < 16) {
+#pragma unroll
+                                for (int m = 0; m < 4; ++m) red[4 * lane + m] = acc[m];
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            Cm += red[lane];
+                            __builtin_amdgcn_wave_barrier();
+                        } else {
+                            if (lane == 0) {
+                                s_nl = nl;
+                                s_nlo = nlo;
+                                s_nle = nle;
+                                s_cmd = 1;
+                            }
+                            __syncthreads();  // (A)
+                            OWN_AXPY_GEN(nlo, nle);
+                            __syncthreads();  // (B)
+                            Cm += reduced(0);
+                        }
+                        OWN_MARK(gi == 0 ? 8 : 2);
+                        ++gi;
+                        if (gi + 2u >= OWN_TAG_SPAN) {
+                            if (lane == 0) {
+                                st(&P.bar[BAR_ERR + 2], 1u);
+                                s_fail = 1;
+                                s_cmd = 2;
+                            }
+                            __syncthreads();  // (A)
+                            return;
+                        }
+                    }
+                    if (lane == 0) s_cmd = 2;
+                    __syncthreads();  // (A) converged: everybody goes on
+                }
+                if (solo && s_fail) return;
+                while (!solo) {
                     const unsigned tag = seq * OWN_TAG_SPAN + gi + 1u;
                     unsigned long long* gbuf = P.gen + (size_t)(gi % OWN_NGEN) * R * G * 2;
                     if (decider) {
@@ -822,6 +976,7 @@ int tsu_dense_own_run(tsu_dense* d, int R_real, const OwnRep* reps, int8_t* stat
     P.rec_from = rec_from;
     P.rec_every = rec_every > 0 ? rec_every : 1;
     P.fail_at = own_env("TSU_K2_OWN_TEST_FAIL", -1);
+    P.solo = own_env("TSU_K2_OWN_SOLO", 1) && NP <= 64;  // (one polled group per lane; the switch is read per call: A/B measurements)
     for (int r = 0; r < R; ++r) P.rep[r] = reps[r < R_real ? r : 0];  // (padding replicas repeat replica 0 on its own state copy: see the caller)
     static const int keep_fields = own_env("TSU_K2_KEEP_FIELDS", 1);
     const bool single = R_real == 1 && allow_persist;
