@@ -327,17 +327,20 @@ def time_sparse_chain(hip, ctx, counters, n=1 << 24):
     ms = ctx.timer_end() / 50
     _, m = g.energy()
     g.close()
-    # a uniform chain's colour classes are REGULAR (csrc/sparse.hip: k5_stencil): no CSR streams, per update two neighbour bits read and
-    # one byte written = 3 B (the general CSR kernel moved 17 + 13 deg = 43 B per update)
-    alg = 3
+    # a uniform chain's colour classes are REGULAR and PAIRED (csrc/sparse.hip: k5_stencil4): no CSR streams; per update two neighbour
+    # bits read, one byte written, and one byte of prepared decisions written (first class) or read (second class) = 4 B (the general
+    # CSR kernel moved 17 + 13 deg = 43 B per update)
+    alg = 4
     gbs = alg * n / (ms * 1e-3) / 1e9
     return {"sites": n, "ms_per_sweep": ms, "spin_updates_per_s": n / (ms * 1e-3),
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "traffic": None,
-                         "note": "regular colour classes (k5_stencil): algorithmic 3 B per update (2 neighbour bits + 1 write) = 25 MB per launch "
-                                 "of one colour class (2^23 sites), so the kernel is bound by instruction issue (one Philox block per update) and "
-                                 "by its two launches per sweep, not by HBM; the round-2 CSR kernel moved 43 B per update (0.52 of the roofline at "
-                                 "9.6e10 updates/s); traffic: not collected for this kernel"},
+                         "note": "regular, paired colour classes (k5_stencil4<1> + <2>): algorithmic 4 B per update = 34 MB per launch of one "
+                                 "colour class (2^23 sites), so the sweep is bound by instruction issue -- ONE Philox block per PAIR of sites "
+                                 "(20 64-bit multiply-adds, ~17 us per 2^23 blocks), computed by the first class's launch, which also prepares "
+                                 "the second class's decisions by neighbour count; the second launch is a 4.4 TB/s byte shuffle (7.7 us) -- "
+                                 "not by HBM; the round-2 CSR kernel moved 43 B per update (0.52 of the roofline at 9.6e10 updates/s); "
+                                 "traffic: not collected for this kernel"},
             "M": m / n}
 
 

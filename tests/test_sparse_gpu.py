@@ -193,3 +193,49 @@ def test_regular_colour_classes_on_the_stencil_kernel_match_the_oracle(shape, n)
     want = ora.sparse_sweep_philox(want, A.indptr, A.indices, A.data, bias, 0.4, 2, 17, sweep0=7, order=order)
     np.testing.assert_array_equal(g.get_state(), want)
     g.close()
+
+
+@pytest.mark.parametrize("n", [300008, 300004, 262144 + 2, 4099])
+@pytest.mark.parametrize("pair,v4,tie", [(1, 1, 0), (0, 1, 0), (1, 0, 0), (1, 1, 1), (0, 1, 1)])
+def test_chain_classes_in_pairs_and_four_positions_per_thread(n, pair, v4, tie, monkeypatch):
+    """The two colour classes of a chain share their Philox blocks index by index: the first class's launch prepares the second
+    class's decisions by neighbour count (k5_stencil4<1> / <2>), four positions per thread when the classes start at multiples
+    of 4 (n = 300008, 262146: both; 300004: the second class starts at 150002 and runs one position per thread on codes written as
+    dwords).  Every combination of the two switches gives the oracle's bits; so does a chain just above the one-workgroup kernel's
+    range (n = 4099 runs k5_small: the switches must not matter there).  tie = 1: every wave takes the 64-bit compares that a draw whose
+    leading 27 bits equal a threshold's needs (one in 2^27: never met by chance in a test)."""
+    from tsu import _hip
+    from tsu.graph import color_graph
+    monkeypatch.setenv("TSU_K5_PAIR", str(pair))
+    monkeypatch.setenv("TSU_K5_V4", str(v4))
+    monkeypatch.setenv("TSU_K5_TEST_TIE", str(tie))
+    A, bias = _regular("chain_edge_bias", n)
+    st = np.random.default_rng(n).integers(0, 2, size=n).astype(np.int8)
+    offsets, order = color_graph(A)
+    g = _hip.SparseSystem(A.indptr, A.indices, A.data, bias, offsets, order)
+    g.set_state(st)
+    g.sweep(0.9, 3, seed=23, sweep0=1)
+    want = ora.sparse_sweep_philox(st, A.indptr, A.indices, A.data, bias, 0.9, 3, 23, sweep0=1, order=order)
+    np.testing.assert_array_equal(g.get_state(), want)
+    got = g.sample(2.5, 2, 1, 2, seed=23, sweep0=4)  # 2 sweeps of burn-in, then a sample after every sweep
+    want = ora.sparse_sweep_philox(want, A.indptr, A.indices, A.data, bias, 2.5, 2, 23, sweep0=4, order=order)
+    for k in range(2):
+        want = ora.sparse_sweep_philox(want, A.indptr, A.indices, A.data, bias, 2.5, 1, 23, sweep0=6 + k, order=order)
+        np.testing.assert_array_equal(got[k], want, err_msg=f"sample {k}")
+    g.close()
+
+
+def test_odd_sites_first_chain_pairs_too():
+    """A colouring that visits the ODD sites first: the pair's first class holds the z, w words' sites, the codes are made from x, y."""
+    from tsu import _hip
+    n = 200000
+    A, bias = _regular("chain", n)
+    order = np.concatenate([np.arange(1, n, 2), np.arange(0, n, 2)]).astype(np.int32)
+    offsets = np.array([0, n // 2, n], np.int32)
+    st = np.random.default_rng(5).integers(0, 2, size=n).astype(np.int8)
+    g = _hip.SparseSystem(A.indptr, A.indices, A.data, bias, offsets, order)
+    g.set_state(st)
+    g.sweep(1.3, 3, seed=29, sweep0=0)
+    want = ora.sparse_sweep_philox(st, A.indptr, A.indices, A.data, bias, 1.3, 3, 29, sweep0=0, order=order)
+    np.testing.assert_array_equal(g.get_state(), want)
+    g.close()

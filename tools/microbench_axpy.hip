@@ -164,6 +164,236 @@ __global__ __launch_bounds__(1024) void axpy_loads(const float* __restrict__ J, 
     if (z == 12345.f) out[threadIdx.x] = z;
 }
 
+
+// V3: the replica layout of k2_own (own_axpy_rep): lane = row (one dword per lane), one entry per wave-instruction, R accumulators
+// per lane with scalar multipliers from the entry's 2-bit codes.  WHAT: 0 = as the kernel runs it, 1 = loads only, 2 = arithmetic
+// only (the same instruction stream on a register value)
+template <int R, int U, int WHAT>
+__global__ __launch_bounds__(1024) void axpy_rep(const float* __restrict__ J, int n, const uint32_t* __restrict__ lists, int nl, int reps,
+                                                 double* __restrict__ out) {
+    __shared__ uint32_t lst[8192];
+    __shared__ double red[16][R][64];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int col = 64 * blockIdx.x + lane;
+    double tot = 0.0;
+    float fake = (float)lane;
+    for (int r = 0; r < reps; ++r) {
+        for (int k = threadIdx.x; k < nl; k += 1024) lst[k] = lists[(size_t)r * nl + k] | (0x5A5Au << 18) | ((k * 2654435761u) & 0xFFFC0000u);
+        __syncthreads();
+        double acc[R];
+#pragma unroll
+        for (int rho = 0; rho < R; ++rho) acc[rho] = 0.0;
+        for (int k = wv; k < nl; k += 16 * U) {
+            float x[U];
+            uint32_t e[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) e[u] = k + 16 * u < nl ? lst[k + 16 * u] : 0u;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (k + 16 * u < nl) {
+                    const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[u]) & 0xFFFFu;
+                    x[u] = WHAT == 2 ? fake + (float)j : J[(size_t)j * n + col];
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (k + 16 * u < nl) {
+                    const uint32_t ev = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[u]);
+                    const double v = (double)x[u];
+                    if (WHAT == 1) {
+                        acc[0] += v;
+                    } else {
+#pragma unroll
+                        for (int rho = 0; rho < R; ++rho) {
+                            const double sg = (double)(((int)(ev << (14 - 2 * rho))) >> 30);
+                            acc[rho] = fma(sg, v, acc[rho]);
+                        }
+                    }
+                }
+        }
+#pragma unroll
+        for (int rho = 0; rho < R; ++rho) red[wv][rho][lane] = acc[rho];
+        __syncthreads();
+        if (wv < R) {
+            double z = 0.0;
+            for (int u = 0; u < 16; ++u) z += red[u][wv][lane];
+            tot += z;
+        }
+        __syncthreads();
+    }
+    if (wv < R) out[(64 * blockIdx.x + lane) * 8 + wv] = tot;
+}
+
+// V4: replicas in the quad layout with PER-LANE multipliers: lane = (quad of rows q < 16, replica pair p < 4); a wave-instruction loads
+// ONE entry's segment four times over (the four replica pairs read the same 256 bytes: one pass through the texture path, no extra
+// memory traffic), 2 replicas x 4 rows of accumulators per lane, multipliers from the lane's own two codes
+template <int U, int WHAT>
+__global__ __launch_bounds__(1024) void axpy_rep_quad(const float* __restrict__ J, int n, const uint32_t* __restrict__ lists, int nl, int reps,
+                                                      double* __restrict__ out) {
+    __shared__ uint32_t lst[8192];
+    __shared__ double red[16][8][64];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int q = lane & 15, p = lane >> 4;
+    const int col0 = 64 * blockIdx.x + 4 * q;
+    double tot = 0.0;
+    for (int r = 0; r < reps; ++r) {
+        for (int k = threadIdx.x; k < nl; k += 1024) lst[k] = lists[(size_t)r * nl + k] | (0x5A5Au << 18) | ((k * 2654435761u) & 0xFFFC0000u);
+        __syncthreads();
+        double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        for (int k = wv; k < nl; k += 16 * U) {
+            float4 x[U];
+            uint32_t e[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) e[u] = k + 16 * u < nl ? lst[k + 16 * u] : 0u;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (k + 16 * u < nl) {
+                    const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[u]) & 0xFFFFu;
+                    x[u] = *reinterpret_cast<const float4*>(J + (size_t)j * n + col0);
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (k + 16 * u < nl) {
+                    if (WHAT == 1) {
+                        acc[0][0] += (double)(x[u].x + x[u].w);
+                    } else {
+                        const uint32_t c4 = e[u] >> (16 + 4 * p);  // my pair's two codes
+                        const double s0 = (double)(((int)(c4 << 30)) >> 30), s1 = (double)(((int)(c4 << 28)) >> 30);
+                        const double v0 = (double)x[u].x, v1 = (double)x[u].y, v2 = (double)x[u].z, v3 = (double)x[u].w;
+                        acc[0][0] = fma(s0, v0, acc[0][0]);
+                        acc[0][1] = fma(s0, v1, acc[0][1]);
+                        acc[0][2] = fma(s0, v2, acc[0][2]);
+                        acc[0][3] = fma(s0, v3, acc[0][3]);
+                        acc[1][0] = fma(s1, v0, acc[1][0]);
+                        acc[1][1] = fma(s1, v1, acc[1][1]);
+                        acc[1][2] = fma(s1, v2, acc[1][2]);
+                        acc[1][3] = fma(s1, v3, acc[1][3]);
+                    }
+                }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) red[wv][2 * p + a][4 * q + m] = acc[a][m];
+        __syncthreads();
+        if (wv < 8) {
+            double z = 0.0;
+            for (int u = 0; u < 16; ++u) z += red[u][wv][lane];
+            tot += z;
+        }
+        __syncthreads();
+    }
+    if (wv < 8) out[(64 * blockIdx.x + lane) * 8 + wv] = tot;
+}
+
+// V5: the replica layout with the multipliers' f64 bit patterns made once per (entry, replica) -- not by a v_cvt_f64_i32 per entry,
+// replica AND wave-instruction.  ALG 1: lane l prepares the high dword for entry l / 8 and replica l % 8 of the round's entries,
+// v_readlane brings it to a scalar register, the multiply-add takes the scalar pair {0, hi}.  ALG 2: a four-entry table in scalar
+// registers indexed through M0 (s_movrels_b32).
+template <int U, int WHAT, int ALG>
+__global__ __launch_bounds__(1024) void axpy_rep2(const float* __restrict__ J, int n, const uint32_t* __restrict__ lists, int nl, int reps,
+                                                  double* __restrict__ out) {
+    constexpr int R = 8;
+    static_assert(U % 8 == 0, "eight entries per multiplier register");
+    __shared__ uint32_t lst[8192 + 16 * 64];
+    __shared__ double red[16][R][64];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int col = 64 * blockIdx.x + lane;
+    double tot = 0.0;
+    float fake = (float)lane;
+    for (int r = 0; r < reps; ++r) {
+        for (int k = threadIdx.x; k < nl; k += 1024) lst[k] = lists[(size_t)r * nl + k] | (0x5A5Au << 18) | ((k * 2654435761u) & 0xFFFC0000u);
+        for (int k = nl + threadIdx.x; k < nl + 16 * U; k += 1024) lst[k] = 0u;  // (entries beyond the list: weight 0)
+        __syncthreads();
+        double acc[R];
+#pragma unroll
+        for (int rho = 0; rho < R; ++rho) acc[rho] = 0.0;
+        for (int k = wv; k < nl; k += 16 * U) {
+            float x[U];
+            uint32_t e[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) e[u] = lst[k + 16 * u];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (k + 16 * u < nl) {
+                    const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[u]) & 0xFFFFu;
+                    x[u] = WHAT == 2 ? fake + (float)j : J[(size_t)j * n + col];
+                }
+            uint32_t mh[U / 8];
+            if (ALG == 1) {
+#pragma unroll
+                for (int h = 0; h < U / 8; ++h) {
+                    const uint32_t ev = lst[k + 16 * (8 * h + (lane >> 3))];
+                    const int t = ((int)(ev << (14 - 2 * (lane & 7)))) >> 30;  // +1, -1, 0
+                    mh[h] = ((uint32_t)t & 0x80000000u) | ((uint32_t)(t & 1) * 0x3FF00000u);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (k + 16 * u < nl) {
+                    const double v = (double)x[u];
+                    if (ALG == 1) {
+#pragma unroll
+                        for (int rho = 0; rho < R; ++rho) {
+                            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)mh[u / 8], (u % 8) * 8 + rho);
+                            acc[rho] = fma(__hiloint2double((int)hi, 0), v, acc[rho]);
+                        }
+                    } else if (ALG == 4) {  // (a floor: the multipliers cost nothing -- one scalar pair per entry for all replicas)
+                        const uint32_t ev = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[u]);
+                        const double sg = __hiloint2double((int)(ev & 0xC0000000u), 0);
+#pragma unroll
+                        for (int rho = 0; rho < R; ++rho) acc[rho] = fma(sg, v, acc[rho]);
+                    } else if (ALG == 5) {  // half of the multipliers by the scalar unit, half by the vector unit (two 32-bit operations each)
+                        const uint32_t ev = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[u]);
+#pragma unroll
+                        for (int rho = 0; rho < R; ++rho) {
+                            const uint32_t src = (rho & 1) ? e[u] : ev;
+                            const uint32_t hi = (src << (14 - 2 * rho)) & 0xC0000000u;
+                            acc[rho] = fma(__hiloint2double((int)hi, 0), v, acc[rho]);
+                        }
+                    } else if (ALG == 3) {
+                        // +-2.0 and 0.0 have the high dwords 0x40000000, 0xC0000000, 0: the sign-extended 2-bit code shifted to the top
+                        // IS the multiplier's high dword (sums come out doubled, exactly: halved at the end)
+                        const uint32_t ev = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[u]);
+#pragma unroll
+                        for (int rho = 0; rho < R; ++rho) {
+                            const uint32_t hi = (ev << (14 - 2 * rho)) & 0xC0000000u;
+                            acc[rho] = fma(__hiloint2double((int)hi, 0), v, acc[rho]);
+                        }
+                    } else {
+                        const uint32_t ev = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[u]);
+                        uint32_t h0, h1, h2, h3, h4, h5, h6, h7;
+                        asm volatile(
+                            "s_mov_b32 s96, 0\n s_mov_b32 s97, 0x3ff00000\n s_mov_b32 s99, 0xbff00000\n"
+                            "s_bfe_u32 m0, %8, 0x20010\n s_nop 0\n s_movrels_b32 %0, s96\n"
+                            "s_bfe_u32 m0, %8, 0x20012\n s_nop 0\n s_movrels_b32 %1, s96\n"
+                            "s_bfe_u32 m0, %8, 0x20014\n s_nop 0\n s_movrels_b32 %2, s96\n"
+                            "s_bfe_u32 m0, %8, 0x20016\n s_nop 0\n s_movrels_b32 %3, s96\n"
+                            "s_bfe_u32 m0, %8, 0x20018\n s_nop 0\n s_movrels_b32 %4, s96\n"
+                            "s_bfe_u32 m0, %8, 0x2001a\n s_nop 0\n s_movrels_b32 %5, s96\n"
+                            "s_bfe_u32 m0, %8, 0x2001c\n s_nop 0\n s_movrels_b32 %6, s96\n"
+                            "s_bfe_u32 m0, %8, 0x2001e\n s_nop 0\n s_movrels_b32 %7, s96\n"
+                            : "=s"(h0), "=s"(h1), "=s"(h2), "=s"(h3), "=s"(h4), "=s"(h5), "=s"(h6), "=s"(h7)
+                            : "s"(ev)
+                            : "m0", "s96", "s97", "s98", "s99");
+                        const uint32_t hh[8] = {h0, h1, h2, h3, h4, h5, h6, h7};
+#pragma unroll
+                        for (int rho = 0; rho < R; ++rho) acc[rho] = fma(__hiloint2double((int)hh[rho], 0), v, acc[rho]);
+                    }
+                }
+        }
+#pragma unroll
+        for (int rho = 0; rho < R; ++rho) red[wv][rho][lane] = acc[rho];
+        __syncthreads();
+        if (wv < R) {
+            double z = 0.0;
+            for (int u = 0; u < 16; ++u) z += red[u][wv][lane];
+            tot += z;
+        }
+        __syncthreads();
+    }
+    if (wv < R) out[(64 * blockIdx.x + lane) * 8 + wv] = tot;
+}
+
 int main(int argc, char** argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 16384;
     const int nl = argc > 2 ? atoi(argv[2]) : 1700;
@@ -188,7 +418,7 @@ int main(int argc, char** argv) {
     CHECK(hipMalloc(&lists, h.size() * 4));
     CHECK(hipMemcpy(lists, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     double* out;
-    CHECK(hipMalloc(&out, (size_t)W * 64 * 8 + 8192));
+    CHECK(hipMalloc(&out, (size_t)W * 64 * 8 * 8 + 8192));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
@@ -197,7 +427,18 @@ int main(int argc, char** argv) {
               {"quad U=2", axpy_quad<2, false>},   {"quad U=3", axpy_quad<3, false>},     {"quad U=6", axpy_quad<6, false>}, {"quad U=1", axpy_quad<1, false>},
               {"loads only U=4", axpy_loads<4>},
               {"quad U=8 nt", axpy_quad<8, true>}, {"quad f32-round U=8", axpy_quad_f32<8>}, {"loads only U=8", axpy_loads<8>},
-              {"loads only U=16", axpy_loads<16>}};
+              {"loads only U=16", axpy_loads<16>},
+              {"rep R=8 U=16", axpy_rep<8, 16, 0>}, {"rep R=8 U=16 loads only", axpy_rep<8, 16, 1>}, {"rep R=8 U=16 arithmetic only", axpy_rep<8, 16, 2>},
+              {"rep R=8 U=8", axpy_rep<8, 8, 0>}, {"rep R=8 U=32", axpy_rep<8, 32, 0>}, {"rep R=2 U=16", axpy_rep<2, 16, 0>},
+              {"rep-quad R=8 U=4", axpy_rep_quad<4, 0>}, {"rep-quad R=8 U=8", axpy_rep_quad<8, 0>}, {"rep-quad R=8 U=8 loads only", axpy_rep_quad<8, 1>},
+              {"rep-quad R=8 U=16", axpy_rep_quad<16, 0>},
+              {"rep2 readlane U=16", axpy_rep2<16, 0, 1>}, {"rep2 readlane U=16 arithmetic only", axpy_rep2<16, 2, 1>},
+              {"rep2 movrels U=16", axpy_rep2<16, 0, 2>}, {"rep2 movrels U=16 arithmetic only", axpy_rep2<16, 2, 2>},
+              {"rep2 pm2 U=16", axpy_rep2<16, 0, 3>}, {"rep2 pm2 U=16 arithmetic only", axpy_rep2<16, 2, 3>}, {"rep2 pm2 U=8", axpy_rep2<8, 0, 3>},
+              {"rep2 pm2 U=24", axpy_rep2<24, 0, 3>},
+              {"rep2 free multipliers U=16", axpy_rep2<16, 0, 4>}, {"rep2 free multipliers U=16 arithmetic only", axpy_rep2<16, 2, 4>},
+              {"rep2 half scalar half vector U=16", axpy_rep2<16, 0, 5>}, {"rep2 half scalar half vector U=16 arithmetic only", axpy_rep2<16, 2, 5>},
+              {"rep2 readlane U=8", axpy_rep2<8, 0, 1>}, {"rep2 movrels U=8", axpy_rep2<8, 0, 2>}};
     if (argc > 5) {  // calibration of the byte counters: ONE launch of the kernel k2_own runs, reading W x nl x reps x 256 bytes
         axpy_quad<4, false><<<W, 1024>>>(J, n, lists, nl, reps, out);
         CHECK(hipDeviceSynchronize());

@@ -32,6 +32,7 @@ struct tsu_sparse {
     // regular colour classes (k5_stencil): see K5Stencil
     std::vector<struct K5Stencil> stencil;  // one per colour; deg < 0: the class is not regular
     unsigned long long* d_thr;              // [n_colors][K5_MAX_DEG + 1] acceptance thresholds of the current call
+    uint8_t* d_code;                        // [n] (position space) decisions prepared for the second class of a PAIR, see K5Stencil::pair
 };
 
 // A REGULAR colour class (chains, rings, ladders ...: `IsingChain`, tsu/models/ising.py:265-286): apart from at most K5_EDGE rows at
@@ -42,6 +43,7 @@ struct tsu_sparse {
 // the device, with the generic kernel's own expressions) from the number of set neighbours.  The end rows run on the generic kernel.
 #define K5_MAX_DEG 4
 #define K5_EDGE 64
+#define K5_THR_STRIDE (2 * (K5_MAX_DEG + 1))  // per class: the thresholds, then their leading 27 bits
 struct K5Stencil {
     int deg;            // -1: not regular
     int pb, pe;         // position range of the class
@@ -49,6 +51,16 @@ struct K5Stencil {
     int off[K5_MAX_DEG];
     double Jv, bias;
     int site0, site_stride;  // site of position p = site0 + site_stride * (p - pb - lo)
+    // PAIRED classes.  The uniform of site i comes from the Philox block of i >> 1 (dense.h: words x, y for the even site, z, w for the
+    // odd one), and in a chain the two sites of a block sit in the two colour classes at the same index: the launch of the first class
+    // (pair = 1) has the second class's uniform in registers for free.  It cannot decide for that site yet -- its neighbours are being
+    // updated -- but the decision is a function of the neighbour count alone: bit k of code[p'] = "the site at position p' of the other
+    // class becomes 1 if k of its neighbours are set".  The second class's launch (pair = 2, k5_paired) computes no random numbers
+    // at all: count, shift, store.  Philox blocks per sweep: one per PAIR of sites instead of one per site.
+    int pair;                // 0: none; 1: prepares the codes of class `other`; 2: consumes them
+    int other;               // the partner class
+    int o_pb, o_lo, o_n;     // (pair = 1) the partner's first position, its leading irregular rows and the number of its REGULAR rows
+    int o_deg;
 };
 
 namespace {
@@ -59,46 +71,195 @@ namespace {
 __global__ void k5_thresholds(int deg, double Jv, double bias, double T, unsigned long long* __restrict__ thr) {
     const int k = threadIdx.x;
     if (k > K5_MAX_DEG) return;
-    if (k > deg) {
-        thr[k] = 0ull;
-        return;
+    unsigned long long t = 0ull;
+    if (k <= deg) {
+        double F = 0.0;
+        for (int i = 0; i < k; ++i) F += Jv * 1.0;
+        F += bias;
+        const double p = sigmoid_clamped(F / T);
+        t = p >= 1.0 ? (1ull << 53) : (unsigned long long)ceil(ldexp(p, 53));
     }
-    double F = 0.0;
-    for (int i = 0; i < k; ++i) F += Jv * 1.0;
-    F += bias;
-    const double p = sigmoid_clamped(F / T);
-    thr[k] = p >= 1.0 ? (1ull << 53) : (unsigned long long)ceil(ldexp(p, 53));
+    thr[k] = t;
+    // its leading 27 bits: for the uniform's leading 27 bits a (m = a 2^26 + b), a < t >> 26 implies m < t and a > t >> 26 implies
+    // m >= t; only a == t >> 26 (one draw in 2^27) needs the 64-bit compare
+    thr[K5_MAX_DEG + 1 + k] = t >> 26;
 }
 
-// one launch per colour class: the regular rows by count and threshold, the few irregular end rows (first and last waves only) by the
-// generic expression on their CSR rows
-__global__ __launch_bounds__(256) void k5_stencil(int8_t* __restrict__ state, K5Stencil S, const unsigned long long* __restrict__ thr,
-                                                  const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col, const double* __restrict__ val,
-                                                  const double* __restrict__ bias, const int32_t* __restrict__ site_of, double T, uint32_t sweep,
-                                                  uint32_t tag, uint32_t k0, uint32_t k1) {
-    const int p = S.pb + (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (p >= S.pe) return;
-    if (p < S.pb + S.lo || p >= S.pe - S.hi) {
+// everything a colour-class launch is given
+struct K5Args {
+    int8_t* state;
+    K5Stencil S;
+    uint8_t* code;                        // (pairs) decisions by neighbour count, position space
+    const int64_t* row_ptr;
+    const int32_t* col;
+    const double* val;
+    const double* bias;
+    const int32_t* site_of;
+    double T;
+    uint32_t sweep, tag, k0, k1;
+    int force_tie;  // (tests) every wave of k5_stencil4 takes the exact 64-bit path
+};
+
+// the code of a partner site from its uniform's 53 bits: bit k = "becomes 1 with k neighbours set"
+static __device__ __forceinline__ uint32_t k5_code(unsigned long long m2, const unsigned long long* __restrict__ thr_other, int o_deg) {
+    uint32_t bits = 0u;
+#pragma unroll
+    for (int i = 0; i <= K5_MAX_DEG; ++i) bits |= (i <= o_deg && m2 < thr_other[i]) ? (1u << i) : 0u;
+    return bits;
+}
+
+// ONE position of a class (index idx inside the class): regular rows by count and threshold, the few irregular end rows by the
+// generic expression on their CSR rows; PAIR: also the code of the other site of the Philox block
+template <bool PAIR>
+static __device__ __forceinline__ void k5_site(const K5Args& A, const unsigned long long* __restrict__ thr, const unsigned long long* __restrict__ thr_other,
+                                               int idx) {
+    const K5Stencil& S = A.S;
+    const int p = S.pb + idx;
+    const bool regular = p >= S.pb + S.lo && p < S.pe - S.hi;
+    // (a paired class: the site number is affine over the WHOLE class, checked at creation)
+    const uint32_t site = (regular || PAIR) ? (uint32_t)(S.site0 + S.site_stride * (p - S.pb - S.lo)) : (uint32_t)A.site_of[p];
+    const u32x4 w = tsu_philox(site >> 1, 0u, A.sweep, A.tag, A.k0, A.k1);  // dense_uniform's block and words (dense.h)
+    const uint32_t a = ((site & 1) ? w.z : w.x) >> 5, b = ((site & 1) ? w.w : w.y) >> 6;
+    if (PAIR) {
+        const int j = idx - S.o_lo;  // the other site of the block: position idx of the partner class
+        if (j >= 0 && j < S.o_n) {
+            const uint32_t a2 = ((site & 1) ? w.x : w.z) >> 5, b2 = ((site & 1) ? w.y : w.w) >> 6;
+            A.code[S.o_pb + idx] = (uint8_t)k5_code(((unsigned long long)a2 << 26) | b2, thr_other, S.o_deg);
+        }
+    }
+    if (!regular) {
         double F = 0.0;
-        for (int64_t e = row_ptr[p]; e < row_ptr[p + 1]; ++e) F += val[e] * (double)state[col[e]];
-        F += bias[p];
-        const double u = dense_uniform((uint32_t)site_of[p], sweep, tag, k0, k1);
-        state[p] = (u < sigmoid_clamped(F / T)) ? 1 : 0;
+        for (int64_t e = A.row_ptr[p]; e < A.row_ptr[p + 1]; ++e) F += A.val[e] * (double)A.state[A.col[e]];
+        F += A.bias[p];
+        const double u = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;  // (dense_uniform)
+        A.state[p] = (u < sigmoid_clamped(F / A.T)) ? 1 : 0;
         return;
     }
     int cnt = 0;
 #pragma unroll
     for (int i = 0; i < K5_MAX_DEG; ++i)
-        if (i < S.deg) cnt += state[p + S.off[i]];
-    const uint32_t site = (uint32_t)(S.site0 + S.site_stride * (p - S.pb - S.lo));
-    const u32x4 w = tsu_philox(site >> 1, 0u, sweep, tag, k0, k1);  // dense_uniform's block and words (dense.h)
-    const uint32_t a = ((site & 1) ? w.z : w.x) >> 5, b = ((site & 1) ? w.w : w.y) >> 6;
+        if (i < S.deg) cnt += A.state[p + S.off[i]];
     const unsigned long long m = ((unsigned long long)a << 26) | b;
     // (the five thresholds sit at uniform addresses: scalar loads issued at the top, selected by the count -- no dependent vector load)
     unsigned long long t = thr[0];
 #pragma unroll
     for (int i = 1; i <= K5_MAX_DEG; ++i) t = cnt == i ? thr[i] : t;
-    state[p] = m < t ? 1 : 0;
+    A.state[p] = m < t ? 1 : 0;
+}
+
+// ONE position of the second class of a pair: its regular rows take the decision the first class's launch prepared (bit `count` of
+// the code); the few irregular end rows run the generic expression
+static __device__ __forceinline__ void k5_site_paired(const K5Args& A, int idx) {
+    const K5Stencil& S = A.S;
+    const int p = S.pb + idx;
+    if (p < S.pb + S.lo || p >= S.pe - S.hi) {
+        double F = 0.0;
+        for (int64_t e = A.row_ptr[p]; e < A.row_ptr[p + 1]; ++e) F += A.val[e] * (double)A.state[A.col[e]];
+        F += A.bias[p];
+        const double u = dense_uniform((uint32_t)A.site_of[p], A.sweep, A.tag, A.k0, A.k1);
+        A.state[p] = (u < sigmoid_clamped(F / A.T)) ? 1 : 0;
+        return;
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < K5_MAX_DEG; ++i)
+        if (i < S.deg) cnt += A.state[p + S.off[i]];
+    A.state[p] = (int8_t)((A.code[p] >> cnt) & 1u);
+}
+
+static __device__ __forceinline__ uint32_t k5_ld4(const void* q) {  // four bytes at any alignment (one dword load: unaligned access mode)
+    uint32_t v;
+    __builtin_memcpy(&v, q, 4);
+    return v;
+}
+
+// One launch per colour class, FOUR consecutive positions per thread: the neighbours' bits arrive as (unaligned) dwords and add up to
+// four byte-wide counts at once, the new bits leave as one dword.  (One position per thread: 3 byte-wide memory instructions per
+// update -- the launch was bound by their issue, not by Philox: 24 us per class of 2^23 sites with or without random numbers.)
+// MODE 0: a class of its own; 1: the first class of a pair (codes for the second); 2: the second class of a pair (no random numbers).
+// The host launches these only for classes whose first position (and, MODE 1, the partner's) is a multiple of 4.  (The thresholds
+// come as __restrict__ kernel arguments: uniform, read-only -- scalar loads at the top; through the struct they became dependent
+// vector loads inside the compare chain, +12 us per launch.)
+template <int MODE>
+__global__ __launch_bounds__(256) void k5_stencil4(K5Args A, const unsigned long long* __restrict__ thr, const unsigned long long* __restrict__ thr_other) {
+    const K5Stencil& S = A.S;
+    const int idx0 = 4 * (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int len = S.pe - S.pb;
+    if (idx0 >= len) return;
+    const bool own4 = idx0 >= S.lo && idx0 + 4 <= len - S.hi;
+    const bool code4 = MODE != 1 || (idx0 >= S.o_lo && idx0 + 4 <= S.o_lo + S.o_n);
+    if (!own4 || !code4) {  // (the end rows' threads: position by position)
+        for (int v = 0; v < 4 && idx0 + v < len; ++v) {
+            if (MODE == 2) k5_site_paired(A, idx0 + v);
+            else if (MODE == 1) k5_site<true>(A, thr, thr_other, idx0 + v);
+            else k5_site<false>(A, thr, thr_other, idx0 + v);
+        }
+        return;
+    }
+    uint32_t tha[K5_MAX_DEG + 1], tho[K5_MAX_DEG + 1];  // the thresholds' leading 27 bits
+#pragma unroll
+    for (int i = 0; i <= K5_MAX_DEG; ++i) {
+        tha[i] = (uint32_t)thr[K5_MAX_DEG + 1 + i];
+        tho[i] = MODE == 1 ? (uint32_t)thr_other[K5_MAX_DEG + 1 + i] : 0u;
+    }
+    const int p0 = S.pb + idx0;
+    uint32_t cnt4 = 0u;  // four counts, one per byte (<= K5_MAX_DEG each)
+#pragma unroll
+    for (int i = 0; i < K5_MAX_DEG; ++i)
+        if (i < S.deg) cnt4 += k5_ld4(A.state + p0 + S.off[i]);
+    uint32_t out = 0u;
+    if (MODE == 2) {
+        const uint32_t c4 = *reinterpret_cast<const uint32_t*>(A.code + p0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) out |= (((c4 >> (8 * v)) & 0xFFu) >> ((cnt4 >> (8 * v)) & 0xFFu) & 1u) << (8 * v);
+    } else {
+        uint32_t codes = 0u;
+        // (compares on the uniforms' leading 27 bits against the thresholds' -- 32-bit operations on scalar operands; the 64-bit
+        // compares of k5_site only for a wave in which some lane's leading bits EQUAL a threshold's: one draw in 2^27)
+        bool tie = A.force_tie != 0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const uint32_t site = (uint32_t)(S.site0 + S.site_stride * (idx0 + v - S.lo));
+            const u32x4 w = tsu_philox(site >> 1, 0u, A.sweep, A.tag, A.k0, A.k1);
+            const uint32_t a = ((site & 1) ? w.z : w.x) >> 5;
+            const uint32_t cnt = (cnt4 >> (8 * v)) & 0xFFu;
+            uint32_t ta = tha[0];
+#pragma unroll
+            for (int i = 1; i <= K5_MAX_DEG; ++i)
+                if (i <= S.deg) ta = cnt == (uint32_t)i ? tha[i] : ta;
+            out |= (a < ta ? 1u : 0u) << (8 * v);
+            tie = tie || a == ta;
+            if (MODE == 1) {
+                const uint32_t a2 = ((site & 1) ? w.x : w.z) >> 5;
+#pragma unroll
+                for (int i = 0; i <= K5_MAX_DEG; ++i)
+                    if (i <= S.o_deg) {
+                        const uint32_t to = tho[i];
+                        codes |= (a2 < to ? 1u : 0u) << (8 * v + i);
+                        tie = tie || a2 == to;
+                    }
+            }
+        }
+        if (__builtin_expect(__any((int)tie), 0)) {
+            for (int v = 0; v < 4; ++v) {
+                if (MODE == 1) k5_site<true>(A, thr, thr_other, idx0 + v);
+                else k5_site<false>(A, thr, thr_other, idx0 + v);
+            }
+            return;
+        }
+        if (MODE == 1) *reinterpret_cast<uint32_t*>(A.code + S.o_pb + idx0) = codes;
+    }
+    *reinterpret_cast<uint32_t*>(A.state + p0) = out;
+}
+
+// the same, one position per thread (classes that do not start at a multiple of 4)
+template <int MODE>
+__global__ __launch_bounds__(256) void k5_stencil1(K5Args A, const unsigned long long* __restrict__ thr, const unsigned long long* __restrict__ thr_other) {
+    const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (idx >= A.S.pe - A.S.pb) return;
+    if (MODE == 2) k5_site_paired(A, idx);
+    else if (MODE == 1) k5_site<true>(A, thr, thr_other, idx);
+    else k5_site<false>(A, thr, thr_other, idx);
 }
 
 // the generic update for an explicit list of rows [p_begin, p_end) -- the irregular end rows of a regular class
@@ -198,7 +359,7 @@ int run_sweeps(tsu_sparse* g, double T, int n_sweeps, uint64_t seed, uint32_t sw
     }
     for (int c = 0; c < g->n_colors; ++c) {  // thresholds of the regular classes at this call's temperature
         const K5Stencil& S = g->stencil[(size_t)c];
-        if (S.deg > 0) hipLaunchKernelGGL(k5_thresholds, dim3(1), dim3(64), 0, ctx->stream, S.deg, S.Jv, S.bias, T, g->d_thr + (size_t)c * (K5_MAX_DEG + 1));
+        if (S.deg > 0) hipLaunchKernelGGL(k5_thresholds, dim3(1), dim3(64), 0, ctx->stream, S.deg, S.Jv, S.bias, T, g->d_thr + (size_t)c * K5_THR_STRIDE);
     }
     for (int s = 0; s < n_sweeps; ++s) {
         for (int c = 0; c < g->n_colors; ++c) {
@@ -206,9 +367,35 @@ int run_sweeps(tsu_sparse* g, double T, int n_sweeps, uint64_t seed, uint32_t sw
             if (pe <= pb) continue;
             const K5Stencil& S = g->stencil[(size_t)c];
             if (S.deg > 0) {
-                hipLaunchKernelGGL(k5_stencil, dim3((unsigned)((pe - pb + 255) / 256)), dim3(256), 0, ctx->stream, g->state, S,
-                                   g->d_thr + (size_t)c * (K5_MAX_DEG + 1), g->row_ptr, g->col, g->val, g->bias, g->site_of, T, sweep0 + (uint32_t)s, tag,
-                                   k0, k1);
+                K5Args A;
+                A.state = g->state;
+                A.S = S;
+                const unsigned long long* thr = g->d_thr + (size_t)c * K5_THR_STRIDE;
+                const unsigned long long* thr_other = S.pair == 1 ? g->d_thr + (size_t)S.other * K5_THR_STRIDE : thr;
+                A.code = g->d_code;
+                A.row_ptr = g->row_ptr;
+                A.col = g->col;
+                A.val = g->val;
+                A.bias = g->bias;
+                A.site_of = g->site_of;
+                A.T = T;
+                A.sweep = sweep0 + (uint32_t)s;
+                A.tag = tag;
+                A.k0 = k0;
+                A.k1 = k1;
+                A.force_tie = getenv("TSU_K5_TEST_TIE") && atoi(getenv("TSU_K5_TEST_TIE")) != 0;
+                const bool use_v4 = !(getenv("TSU_K5_V4") && atoi(getenv("TSU_K5_V4")) == 0);
+                const bool v4 = use_v4 && pb % 4 == 0 && (S.pair != 1 || S.o_pb % 4 == 0);
+                const dim3 grid((unsigned)(((pe - pb + (v4 ? 3 : 0)) / (v4 ? 4 : 1) + 255) / 256));
+                if (v4) {
+                    if (S.pair == 2) hipLaunchKernelGGL(k5_stencil4<2>, grid, dim3(256), 0, ctx->stream, A, thr, thr_other);
+                    else if (S.pair == 1) hipLaunchKernelGGL(k5_stencil4<1>, grid, dim3(256), 0, ctx->stream, A, thr, thr_other);
+                    else hipLaunchKernelGGL(k5_stencil4<0>, grid, dim3(256), 0, ctx->stream, A, thr, thr_other);
+                } else {
+                    if (S.pair == 2) hipLaunchKernelGGL(k5_stencil1<2>, grid, dim3(256), 0, ctx->stream, A, thr, thr_other);
+                    else if (S.pair == 1) hipLaunchKernelGGL(k5_stencil1<1>, grid, dim3(256), 0, ctx->stream, A, thr, thr_other);
+                    else hipLaunchKernelGGL(k5_stencil1<0>, grid, dim3(256), 0, ctx->stream, A, thr, thr_other);
+                }
                 continue;
             }
             hipLaunchKernelGGL(k5_color, dim3((unsigned)((pe - pb + 255) / 256)), dim3(256), 0, ctx->stream, g->row_ptr, g->col, g->val, g->bias,
@@ -224,7 +411,7 @@ int run_sweeps(tsu_sparse* g, double T, int n_sweeps, uint64_t seed, uint32_t sw
 }
 
 void free_all(tsu_sparse* g) {
-    void* ptrs[] = {g->row_ptr, g->col, g->val, g->bias, g->site_of, g->pos_of, g->state, g->staging, g->samples, g->d_red, g->d_thr};
+    void* ptrs[] = {g->row_ptr, g->col, g->val, g->bias, g->site_of, g->pos_of, g->state, g->staging, g->samples, g->d_red, g->d_thr, g->d_code};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete g;
@@ -285,8 +472,9 @@ int tsu_sparse_create(tsu_ctx* ctx, int n, const int64_t* row_ptr, const int32_t
     g->n_colors = n_colors;
     g->nnz = nnz;
     g->d_thr = nullptr;
+    g->d_code = nullptr;
     // regular colour classes: the pattern of the class's middle row must hold for every row but at most K5_EDGE at either end
-    static const bool use_stencil = !(getenv("TSU_K5_STENCIL") && atoi(getenv("TSU_K5_STENCIL")) == 0);
+    const bool use_stencil = !(getenv("TSU_K5_STENCIL") && atoi(getenv("TSU_K5_STENCIL")) == 0);
     g->stencil.assign((size_t)n_colors, K5Stencil());
     for (int c = 0; c < n_colors; ++c) {
         K5Stencil& S = g->stencil[(size_t)c];
@@ -323,7 +511,38 @@ int tsu_sparse_create(tsu_ctx* ctx, int n, const int64_t* row_ptr, const int32_t
         T.lo = lo;
         T.hi = hi;
         T.site0 = order[pb + lo];
+        T.pair = 0;
+        T.other = -1;
+        T.o_pb = T.o_lo = T.o_n = T.o_deg = 0;
         S = T;
+    }
+    // pairs of regular classes that share their Philox blocks index by index (K5Stencil::pair): sites ascending by 2 over the WHOLE
+    // class (end rows included), the first sites of the two classes are the two sites of one block, and every regular row of the
+    // second class has its partner in the first
+    const bool use_pairs = !(getenv("TSU_K5_PAIR") && atoi(getenv("TSU_K5_PAIR")) == 0);
+    bool any_pair = false;
+    for (int c = 0; c < n_colors && use_pairs; ++c) {
+        K5Stencil& A = g->stencil[(size_t)c];
+        if (A.deg <= 0 || A.pair || A.site_stride != 2) continue;
+        for (int c2 = c + 1; c2 < n_colors; ++c2) {
+            K5Stencil& B = g->stencil[(size_t)c2];
+            if (B.deg <= 0 || B.pair || B.site_stride != 2) continue;
+            if ((order[A.pb] ^ 1) != order[B.pb]) continue;
+            bool ok = true;
+            for (int q = A.pb; q < A.pe && ok; ++q) ok = order[q] == order[A.pb] + 2 * (q - A.pb);
+            for (int q = B.pb; q < B.pe && ok; ++q) ok = order[q] == order[B.pb] + 2 * (q - B.pb);
+            if (!ok || (B.pe - B.hi) - B.pb > A.pe - A.pb) continue;  // (a regular row of B beyond A's last index would have no code)
+            A.pair = 1;
+            A.other = c2;
+            A.o_pb = B.pb;
+            A.o_lo = B.lo;
+            A.o_n = (B.pe - B.hi) - (B.pb + B.lo);
+            A.o_deg = B.deg;
+            B.pair = 2;
+            B.other = c;
+            any_pair = true;
+            break;
+        }
     }
     g->color_off.assign(color_offsets, color_offsets + n_colors + 1);
     hipError_t e = hipSuccess;
@@ -346,7 +565,8 @@ int tsu_sparse_create(tsu_ctx* ctx, int n, const int64_t* row_ptr, const int32_t
     if (e == hipSuccess) e = hipMemsetAsync(g->state, 0, (size_t)n, ctx->stream);
     if (e == hipSuccess) e = hipMalloc((void**)&g->staging, (size_t)n);
     if (e == hipSuccess) e = hipMalloc((void**)&g->d_red, 2 * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&g->d_thr, (size_t)n_colors * (K5_MAX_DEG + 1) * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&g->d_thr, (size_t)n_colors * K5_THR_STRIDE * sizeof(unsigned long long));
+    if (e == hipSuccess && any_pair) e = hipMalloc((void**)&g->d_code, (size_t)n);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the host vectors go out of scope
     if (e != hipSuccess) {
         free_all(g);
