@@ -289,7 +289,7 @@ __global__ __launch_bounds__(1024) void axpy_rep_quad(const float* __restrict__ 
 // replica AND wave-instruction.  ALG 1: lane l prepares the high dword for entry l / 8 and replica l % 8 of the round's entries,
 // v_readlane brings it to a scalar register, the multiply-add takes the scalar pair {0, hi}.  ALG 2: a four-entry table in scalar
 // registers indexed through M0 (s_movrels_b32).
-template <int U, int WHAT, int ALG>
+template <int U, int WHAT, int ALG, int NS = 4>
 __global__ __launch_bounds__(1024) void axpy_rep2(const float* __restrict__ J, int n, const uint32_t* __restrict__ lists, int nl, int reps,
                                                   double* __restrict__ out) {
     constexpr int R = 8;
@@ -342,6 +342,16 @@ __global__ __launch_bounds__(1024) void axpy_rep2(const float* __restrict__ J, i
                         const double sg = __hiloint2double((int)(ev & 0xC0000000u), 0);
 #pragma unroll
                         for (int rho = 0; rho < R; ++rho) acc[rho] = fma(sg, v, acc[rho]);
+                    } else if (ALG == 6) {  // NS multipliers by the scalar unit, R - NS by the vector unit (the entry through an opaque VGPR)
+                        const uint32_t ev = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[u]);
+                        uint32_t evv = e[u];
+                        asm volatile("; opaque %0" : "+v"(evv));
+#pragma unroll
+                        for (int rho = 0; rho < R; ++rho) {
+                            const uint32_t src = rho < NS ? ev : evv;
+                            const uint32_t hi = (src << (14 - 2 * rho)) & 0xC0000000u;
+                            acc[rho] = fma(__hiloint2double((int)hi, 0), v, acc[rho]);
+                        }
                     } else if (ALG == 5) {  // half of the multipliers by the scalar unit, half by the vector unit (two 32-bit operations each)
                         const uint32_t ev = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[u]);
 #pragma unroll
@@ -438,6 +448,11 @@ int main(int argc, char** argv) {
               {"rep2 pm2 U=24", axpy_rep2<24, 0, 3>},
               {"rep2 free multipliers U=16", axpy_rep2<16, 0, 4>}, {"rep2 free multipliers U=16 arithmetic only", axpy_rep2<16, 2, 4>},
               {"rep2 half scalar half vector U=16", axpy_rep2<16, 0, 5>}, {"rep2 half scalar half vector U=16 arithmetic only", axpy_rep2<16, 2, 5>},
+              {"rep2 0 scalar 8 vector", axpy_rep2<16, 0, 6, 0>}, {"rep2 0 scalar 8 vector arithmetic only", axpy_rep2<16, 2, 6, 0>},
+              {"rep2 2 scalar 6 vector", axpy_rep2<16, 0, 6, 2>}, {"rep2 2 scalar 6 vector arithmetic only", axpy_rep2<16, 2, 6, 2>},
+              {"rep2 3 scalar 5 vector", axpy_rep2<16, 0, 6, 3>}, {"rep2 3 scalar 5 vector arithmetic only", axpy_rep2<16, 2, 6, 3>},
+              {"rep2 4 scalar 4 vector", axpy_rep2<16, 0, 6, 4>}, {"rep2 4 scalar 4 vector arithmetic only", axpy_rep2<16, 2, 6, 4>},
+              {"rep2 5 scalar 3 vector", axpy_rep2<16, 0, 6, 5>}, {"rep2 5 scalar 3 vector arithmetic only", axpy_rep2<16, 2, 6, 5>},
               {"rep2 readlane U=8", axpy_rep2<8, 0, 1>}, {"rep2 movrels U=8", axpy_rep2<8, 0, 2>}};
     if (argc > 5) {  // calibration of the byte counters: ONE launch of the kernel k2_own runs, reading W x nl x reps x 256 bytes
         axpy_quad<4, false><<<W, 1024>>>(J, n, lists, nl, reps, out);
