@@ -201,6 +201,32 @@ def time_langevin(hip, ctx, counters):
         "element_steps_per_s": chains * dim * steps / (ms * 1e-3), "us_per_launch": ms * 1e3 / steps,
         "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": tr,
                      "note": "algorithmic 8 B per element-step (fp32 read + write) x 2^28 elements per launch; traffic: PMC bytes per launch"}}
+    # coupled quadratic energy E = 1/2 x^T A x (k3_coupled): one chain at d = 16384 is a matrix-vector product per step, A (1 GiB)
+    # streamed once = 4 B per element of A and step
+    d2, steps = 16384, 30
+    A = np.zeros((d2, d2), np.float32)
+    A[np.arange(d2), np.arange(d2)] = 2.0
+    i = np.arange(d2 - 1)
+    A[i, i + 1] = A[i + 1, i] = 0.5
+    lc = hip.LangevinChains(1, d2, ctx=ctx)
+    lc.set_coupling(A)
+    del A
+    lc.set_state(np.zeros((1, d2), np.float32))
+    lc.step(5, 0.01, 1.0, 1.0, 7, 0)
+    ctx.synchronize()
+    ms = 1e30
+    for rep in range(3):
+        ctx.timer_begin()
+        lc.step(steps, 0.01, 1.0, 1.0, 7, 5 + rep * steps)
+        ms = min(ms, ctx.timer_end())
+    var = float(lc.get_state().var())
+    lc.close()
+    gbs = 4.0 * d2 * d2 * steps / (ms * 1e-3) / 1e9
+    out["coupled_quadratic_d16384_one_chain"] = {
+        "us_per_step": ms * 1e3 / steps, "element_steps_per_s": d2 * steps / (ms * 1e-3), "variance": var,
+        "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                     "note": "k3_coupled, one launch per step: algorithmic d^2 x 4 B per step (the symmetric matrix streamed once, gradient "
+                             "A x + b as an axpy over its rows); best of 3 calls of 30 steps; traffic: not collected"}}
     return out
 
 

@@ -356,6 +356,22 @@ def langevin_quadratic_f32(x, k, mu, n_steps, dt, gamma, T, seed, step0=0, chain
     return (xx, traj) if trajectory else xx
 
 
+def langevin_coupled_f32(x, A, b, n_steps, dt, gamma, T, seed, step0=0, chain0=0, trajectory=False):
+    """Langevin steps on E = 1/2 x^T A x + b^T x (A symmetric (dim, dim)); x: (n_chains, dim) float32.  Returns x_final or
+    (x_final, traj (n_steps, n_chains, dim))."""
+    xx = np.ascontiguousarray(x, dtype=np.float32).copy()
+    if xx.ndim == 1:
+        xx = xx[None, :]
+    n_chains, dim = xx.shape
+    aa = np.ascontiguousarray(A, dtype=np.float32).reshape(dim, dim)
+    bb = None if b is None else np.ascontiguousarray(np.broadcast_to(np.asarray(b, dtype=np.float32), (dim,)))
+    traj = np.zeros((n_steps, n_chains, dim), dtype=np.float32) if trajectory else None
+    lib().ora_langevin_coupled_f32(_p(xx, C.c_float), _p(aa, C.c_float), None if bb is None else _p(bb, C.c_float), C.c_int(n_chains),
+                                   C.c_int(dim), C.c_int(n_steps), C.c_float(dt), C.c_float(gamma), C.c_float(T), C.c_uint64(seed),
+                                   C.c_uint32(step0), C.c_uint32(chain0), None if traj is None else _p(traj, C.c_float))
+    return (xx, traj) if trajectory else xx
+
+
 def ising2d_site_uniforms(rows, cols, hs, seed, replica=0):
     """(rows, cols) uint32: the uniform each site uses in half-sweep hs = 2*sweep + colour."""
     out = np.zeros((rows, cols), dtype=np.uint32)

@@ -25,6 +25,7 @@
  *        - ora_ising2d_randomize / ora_ising2d_sweep / ora_ising2d_observables
  *        - ora_dense_sweep_philox, ora_sparse_sweep_philox (the same loop on a CSR graph, coloured visiting order)
  *        - ora_langevin_quadratic_f32
+ *        - ora_langevin_coupled_f32   (analytic gradient of a coupled quadratic; tsu/core.py:82-98,146-150)
  */
 #include <math.h>
 #include <stdint.h>
@@ -361,6 +362,35 @@ void ora_langevin_quadratic_f32(float *x, const float *k, const float *mu, int n
                 x[idx] = v;
                 if (traj) traj[((size_t)s * n_chains + ch) * dim + i] = v;
             }
+}
+
+
+/*
+ * The same for a COUPLED quadratic energy E = 1/2 x^T A x + b^T x (A symmetric, dim*dim row-major): grad = A x + b, the analytic form
+ * of what the reference's central differences (tsu/core.py:82-98) return for such an energy.  Every element of the new state is
+ * computed from the whole OLD state (core.py:146-150: the gradient is taken at x, then x is replaced).  The dot products are
+ * accumulated in double and rounded to float once -- the device sums in float in its own order: tolerance in the tests.
+ */
+void ora_langevin_coupled_f32(float *x, const float *A, const float *b, int n_chains, int dim, int n_steps, float dt, float gamma,
+                              float T, uint64_t seed, uint32_t step0, uint32_t chain0, float *traj) {
+    float scale = sqrtf(2.0f * T * dt / gamma);
+    float a = dt / gamma;
+    float *xn = (float *)malloc((size_t)dim * sizeof(float));
+    for (int s = 0; s < n_steps; ++s)
+        for (int ch = 0; ch < n_chains; ++ch) {
+            float *xc = x + (size_t)ch * dim;
+            for (int i = 0; i < dim; ++i) {
+                float nrm[4];
+                ora_langevin_normals_f32((uint32_t)i >> 2, chain0 + (uint32_t)ch, step0 + (uint32_t)s, TAG_LANGEVIN, seed, nrm);
+                double acc = 0.0;
+                for (int j = 0; j < dim; ++j) acc += (double)A[(size_t)i * dim + j] * (double)xc[j];
+                float g = (float)(acc + (b ? (double)b[i] : 0.0));
+                xn[i] = fmaf(scale, nrm[i & 3], fmaf(-g, a, xc[i]));
+            }
+            memcpy(xc, xn, (size_t)dim * sizeof(float));
+            if (traj) memcpy(traj + ((size_t)s * n_chains + ch) * dim, xn, (size_t)dim * sizeof(float));
+        }
+    free(xn);
 }
 
 /* test helper: the 32-bit uniform every site would use in half-sweep hs (row-major, rows*cols) */

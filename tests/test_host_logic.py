@@ -387,3 +387,51 @@ def test_frozen_arrays_skip_the_content_hash_and_thawed_ones_do_not(monkeypatch)
     J *= 2.0
     J.setflags(write=False)
     assert s._system(J, None).J[0, 0] == J[0, 0] and FakeSystem.built == built + 1
+
+
+def test_coupled_langevin_twin_is_the_plain_formula():
+    """oracle ora_langevin_coupled_f32 == x + (-(A x + b) dt / gamma) + sqrt(2 T dt / gamma) xi with the K3 normals, every element
+    from the OLD state (tsu/core.py:146-150), in float32 with the gradient rounded once."""
+    from oracle import oracle as ora
+    rng = np.random.default_rng(3)
+    d, chains = 7, 2
+    A = rng.standard_normal((d, d)).astype(np.float32)
+    A = np.triu(A) + np.triu(A, 1).T + 4 * np.eye(d, dtype=np.float32)
+    b = rng.standard_normal(d).astype(np.float32)
+    x = rng.standard_normal((chains, d)).astype(np.float32)
+    got, traj = ora.langevin_coupled_f32(x, A, b, 3, 0.01, 2.0, 0.5, 77, step0=4, chain0=1, trajectory=True)
+    want = x.copy()
+    a, scale = np.float32(0.01) / np.float32(2.0), np.sqrt(np.float32(2.0) * np.float32(0.5) * np.float32(0.01) / np.float32(2.0))
+    for s in range(3):
+        for c in range(chains):
+            g = (A.astype(np.float64) @ want[c].astype(np.float64) + b.astype(np.float64)).astype(np.float32)
+            xi = np.concatenate([ora.langevin_normals_f32(q, 1 + c, 4 + s, 77) for q in range((d + 3) // 4)])[:d]
+            drift = (want[c].astype(np.float64) + (-g.astype(np.float64)) * np.float64(a)).astype(np.float32)  # fmaf(-g, a, x)
+            want[c] = (drift.astype(np.float64) + np.float64(scale) * xi.astype(np.float64)).astype(np.float32)  # fmaf(scale, xi, .)
+        np.testing.assert_array_equal(traj[s], want)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_coupled_quadratics_are_recognised_by_probing_and_others_are_not():
+    from tsu import core
+    M = np.array([[2.0, 0.5, 0.0], [0.5, 1.0, -0.25], [0.0, -0.25, 1.5]])
+    v = np.array([1.0, 0.0, -0.5])
+    q = core._recognise_quadratic(lambda x: float(0.5 * x @ M @ x + v @ x + 3.0), np.array([0.3, -0.2, 0.1]))
+    assert isinstance(q, core.QuadraticForm)
+    np.testing.assert_allclose(q.A, M, atol=1e-12)
+    np.testing.assert_allclose(q.b, v, atol=1e-12)
+    assert abs(q.c - 3.0) < 1e-9
+    # separable ones stay on the separable descriptor
+    assert isinstance(core._recognise_quadratic(lambda x: float((x ** 2).sum()), np.zeros(3)), core.QuadraticEnergy)
+    # not quadratic, indefinite, too large for the coupled probe: host path
+    assert core._recognise_quadratic(lambda x: float(np.sum(x ** 4) + x[0] * x[1]), np.zeros(3)) is None
+    assert core._recognise_quadratic(lambda x: float(x[0] * x[1]), np.zeros(2)) is None
+    big = np.eye(80) + 0.01
+    assert core._recognise_quadratic(lambda x: float(0.5 * x @ big @ x), np.zeros(80)) is None
+    # the descriptor: symmetric part, call, gradient
+    f = core.QuadraticForm([[1.0, 1.0], [0.0, 2.0]], [1.0, -1.0], 0.5)
+    x = np.array([2.0, 3.0])
+    assert f(x) == 0.5 * (1 * 4 + 1 * 6 + 2 * 9) + (2 - 3) + 0.5
+    np.testing.assert_array_equal(f.gradient(x), np.array([[1.0, 0.5], [0.5, 2.0]]) @ x + [1.0, -1.0])
+    with pytest.raises(core.ConfigurationError):
+        core.QuadraticForm(np.zeros((2, 3)))

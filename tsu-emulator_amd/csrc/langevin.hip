@@ -13,6 +13,17 @@
 //   pair p in {0,1}: u1 = ((W[2p] >> 8) + 1) / 2^24, u2 = (W[2p+1] >> 8) / 2^24,
 //   xi[2p] = sqrt(-2 ln u1) cos(2 pi u2), xi[2p+1] = sqrt(-2 ln u1) sin(2 pi u2);
 //   x <- fma(sqrt(2 T dt / gamma), xi, fma(-k (x - mu), dt / gamma, x)).
+//
+// COUPLED quadratic energies E = 1/2 x^T A x + b^T x (A symmetric; the shape of the reference's multivariate callers,
+// tsu/api.py:94): k3_coupled, one launch per step, gradient g = A x + b as an axpy over the rows of A (A^T = A: row j of A
+// is column j, so F[i] += A[j, i] x[j] reads contiguous segments -- the layout of the dense Gibbs kernel's axpy pass,
+// dense_own.hip): a workgroup owns 64 rows of the result for CB chains, a lane a quad of rows and one of four entry slots, the
+// chains' states sit transposed in LDS ([j][chain]: two 16-byte reads give eight chains' x_j).  A is read once per block of CB
+// chains: n_chains = 1 is a GEMV at the HBM roofline (4 B per element of A and step); many chains (the restarts of
+// sample_from_energy) reuse A from L2.  Same noise stream and update expression as the separable kernel.
+// CPU twin: oracle/tsu_oracle.c ora_langevin_coupled_f32 (gradient accumulated in f64, rounded to f32: tolerance in the tests).
+#include <utility>
+
 #include "tsu_common.h"
 
 struct tsu_langevin {
@@ -23,7 +34,11 @@ struct tsu_langevin {
     float* mu;
     float* xinit;
     int steps_per_launch;
-    int have_energy;
+    int have_energy;  // 0: none; 1: separable (k, mu); 2: coupled (A, b)
+    float* A;         // [P][P], P = dim rounded up to 64, zero padded
+    float* b;         // [P]
+    float* x2;        // the other buffer of a coupled step (every element of the new state needs the whole old one)
+    int P;
 };
 
 static __device__ __forceinline__ void box_muller4(const u32x4& w, float n[4]) {
@@ -65,6 +80,101 @@ __global__ __launch_bounds__(256) void k3_langevin(float* __restrict__ x, const 
     *px = xv;
 }
 
+
+// ---- coupled quadratic energy: one step.  Grid (P / 64, ceil(n_chains / CB)), 1024 threads.
+#define K3C_THREADS 1024
+#define K3C_WAVES 16
+template <int CB>
+__global__ __launch_bounds__(K3C_THREADS) void k3_coupled(const float* __restrict__ xin, float* __restrict__ xout, const float* __restrict__ A,
+                                                          const float* __restrict__ bvec, int n_chains, int dim, int pitch, int P, float a,
+                                                          float scale, uint32_t k0, uint32_t k1, uint32_t step, uint32_t chain0,
+                                                          float* __restrict__ traj) {
+    extern __shared__ float k3c_lds[];
+    float* xT = k3c_lds;                    // [P][CB] the chains' states, chain fastest
+    float* red = xT + (size_t)P * CB;       // [K3C_WAVES][CB][64]
+    const int rb = (int)blockIdx.x, c0 = (int)blockIdx.y * CB;
+    for (int q = (int)threadIdx.x; q < P * CB; q += K3C_THREADS) {
+        const int j = q / CB, c = q - j * CB;
+        xT[q] = (j < dim && c0 + c < n_chains) ? xin[(size_t)(c0 + c) * pitch + j] : 0.0f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int q16 = lane & 15, t = lane >> 4;
+    const int col0 = 64 * rb + 4 * q16;
+    float acc[CB][4];
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[c][m] = 0.0f;
+    constexpr int U = 4;  // bundles (4 rows of A each) in flight per lane
+    const int nb = P / 4;  // (a multiple of 16)
+    for (int bnd = wv; bnd < nb; bnd += K3C_WAVES * U) {
+        float4 av[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (bnd + K3C_WAVES * u < nb) av[u] = *reinterpret_cast<const float4*>(A + (size_t)(4 * (bnd + K3C_WAVES * u) + t) * P + col0);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (bnd + K3C_WAVES * u < nb) {
+                const float* xs = xT + (size_t)(4 * (bnd + K3C_WAVES * u) + t) * CB;
+#pragma unroll
+                for (int c = 0; c < CB; ++c) {
+                    const float xv = xs[c];
+                    acc[c][0] = __fmaf_rn(av[u].x, xv, acc[c][0]);
+                    acc[c][1] = __fmaf_rn(av[u].y, xv, acc[c][1]);
+                    acc[c][2] = __fmaf_rn(av[u].z, xv, acc[c][2]);
+                    acc[c][3] = __fmaf_rn(av[u].w, xv, acc[c][3]);
+                }
+            }
+    }
+    // the four entry slots of a quad (fixed order), then the sixteen waves through LDS
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            float z = acc[c][m];
+            z += __shfl_xor(z, 16, 64);
+            z += __shfl_xor(z, 32, 64);
+            acc[c][m] = z;
+        }
+    if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < CB; ++c)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) red[(wv * CB + c) * 64 + 4 * lane + m] = acc[c][m];
+    }
+    __syncthreads();
+    for (int q = (int)threadIdx.x; q < CB * 64; q += K3C_THREADS) {
+        const int c = q >> 6, r = q & 63;
+        const int i = 64 * rb + r, ch = c0 + c;
+        if (i >= dim || ch >= n_chains) continue;
+        float g = 0.0f;
+#pragma unroll
+        for (int w = 0; w < K3C_WAVES; ++w) g += red[(w * CB + c) * 64 + r];
+        g += bvec[i];
+        const u32x4 wd = tsu_philox((uint32_t)i >> 2, chain0 + (uint32_t)ch, step, TSU_TAG_LANGEVIN, k0, k1);
+        float n[4];
+        box_muller4(wd, n);
+        const float nz = (i & 3) == 0 ? n[0] : (i & 3) == 1 ? n[1] : (i & 3) == 2 ? n[2] : n[3];
+        const float v = __fmaf_rn(scale, nz, __fmaf_rn(-g, a, xT[(size_t)i * CB + c]));
+        xout[(size_t)ch * pitch + i] = v;
+        if (traj) traj[(size_t)ch * pitch + i] = v;
+    }
+}
+
+template <int CB>
+static hipError_t k3c_launch(tsu_langevin* l, const float* xin, float* xout, float a, float scale, uint64_t seed, uint32_t step, uint32_t chain0,
+                             float* traj) {
+    tsu_ctx* ctx = l->ctx;
+    const size_t lds = ((size_t)l->P * CB + (size_t)K3C_WAVES * CB * 64) * sizeof(float);
+    hipError_t e = tsu_func_allow_lds(ctx, (const void*)k3_coupled<CB>, (int)lds);
+    if (e != hipSuccess) return e;
+    const dim3 grid((unsigned)(l->P / 64), (unsigned)((l->n_chains + CB - 1) / CB));
+    hipLaunchKernelGGL(k3_coupled<CB>, grid, dim3(K3C_THREADS), lds, ctx->stream, xin, xout, l->A, l->b, l->n_chains, l->dim, l->pitch, l->P, a, scale,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), step, chain0, traj);
+    return hipGetLastError();
+}
+
 // x[c] <- x_init + amp * N(0,1), chain id chain0 + c (core.py:142-143)
 __global__ __launch_bounds__(256) void k3_restart(float* __restrict__ x, const float* __restrict__ xinit, int n_chains,
                                                  int quads, int pitch, float amp, uint32_t k0, uint32_t k1,
@@ -95,6 +205,8 @@ int tsu_langevin_create(tsu_ctx* ctx, int n_chains, int dim, tsu_langevin** out)
     l->dim = dim;
     l->pitch = (dim + 3) / 4 * 4;
     l->x = l->k = l->mu = l->xinit = nullptr;
+    l->A = l->b = l->x2 = nullptr;
+    l->P = (dim + 63) / 64 * 64;
     l->steps_per_launch = 0;
     l->have_energy = 0;
     size_t xb = (size_t)n_chains * l->pitch * sizeof(float), vb = (size_t)l->pitch * sizeof(float);
@@ -121,7 +233,7 @@ int tsu_langevin_destroy(tsu_langevin* l) {
     TSU_ENTER(l ? l->ctx : nullptr);
     if (!l) return TSU_OK;
     (void)hipStreamSynchronize(l->ctx->stream);
-    for (float* p : {l->x, l->k, l->mu, l->xinit})
+    for (float* p : {l->x, l->k, l->mu, l->xinit, l->A, l->b, l->x2})
         if (p) (void)hipFree(p);
     delete l;
     return TSU_OK;
@@ -158,6 +270,33 @@ int tsu_langevin_set_energy(tsu_langevin* l, const float* k_host, const float* m
     TSU_HIP_TRY(l->ctx, hipMemcpyAsync(l->mu, mu_host, w, hipMemcpyHostToDevice, l->ctx->stream));
     TSU_HIP_TRY(l->ctx, hipStreamSynchronize(l->ctx->stream));
     l->have_energy = 1;
+    return TSU_OK;
+}
+
+int tsu_langevin_set_coupling(tsu_langevin* l, const float* A_host, const float* b_host) {
+    TSU_ENTER(l ? l->ctx : nullptr);
+    if (!l) return TSU_E_INVALID;
+    tsu_ctx* ctx = l->ctx;
+    TSU_REQUIRE(ctx, A_host != nullptr, "langevin_set_coupling: NULL matrix");
+    const int d = l->dim, P = l->P;
+    // chains per workgroup are bounded by the LDS (the states of a block of chains, all P columns): P <= 32768 for one chain
+    TSU_REQUIRE(ctx, (size_t)P * 4 + (size_t)K3C_WAVES * 64 * 4 <= 150 * 1024, "langevin_set_coupling: dim %d is beyond the coupled kernel's range (32768)", d);
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < i; ++j)
+            TSU_REQUIRE(ctx, A_host[(size_t)i * d + j] == A_host[(size_t)j * d + i], "langevin_set_coupling: the matrix must be symmetric (entry %d, %d)", i, j);
+    if (!l->A) {
+        TSU_HIP_TRY(ctx, hipMalloc(&l->A, (size_t)P * P * sizeof(float)));
+        TSU_HIP_TRY(ctx, hipMalloc(&l->b, (size_t)P * sizeof(float)));
+        TSU_HIP_TRY(ctx, hipMalloc(&l->x2, (size_t)l->n_chains * l->pitch * sizeof(float)));
+        TSU_HIP_TRY(ctx, hipMemsetAsync(l->x2, 0, (size_t)l->n_chains * l->pitch * sizeof(float), ctx->stream));
+    }
+    TSU_HIP_TRY(ctx, hipMemsetAsync(l->A, 0, (size_t)P * P * sizeof(float), ctx->stream));
+    TSU_HIP_TRY(ctx, hipMemsetAsync(l->b, 0, (size_t)P * sizeof(float), ctx->stream));
+    TSU_HIP_TRY(ctx, hipMemcpy2DAsync(l->A, (size_t)P * sizeof(float), A_host, (size_t)d * sizeof(float), (size_t)d * sizeof(float), (size_t)d,
+                                      hipMemcpyHostToDevice, ctx->stream));
+    if (b_host) TSU_HIP_TRY(ctx, hipMemcpyAsync(l->b, b_host, (size_t)d * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    l->have_energy = 2;
     return TSU_OK;
 }
 
@@ -200,14 +339,30 @@ int tsu_langevin_step(tsu_langevin* l, int n_steps, float dt, float gamma, float
     unsigned grid = (unsigned)((total + 255) / 256);
     float* d_traj = nullptr;
     if (traj_host) TSU_HIP_TRY(ctx, hipMalloc(&d_traj, (size_t)n_steps * l->n_chains * l->pitch * sizeof(float)));
-    int per = l->steps_per_launch > 0 ? l->steps_per_launch : n_steps;
-    for (int s = 0; s < n_steps; s += per) {
-        int ns = n_steps - s < per ? n_steps - s : per;
-        k3_langevin<<<grid, 256, 0, ctx->stream>>>(l->x, l->k, l->mu, l->n_chains, quads, l->pitch, ns, a, scale, (uint32_t)seed,
-                                                   (uint32_t)(seed >> 32), step0 + (uint32_t)s, chain0,
-                                                   d_traj ? d_traj + (size_t)s * l->n_chains * l->pitch : nullptr);
+    hipError_t e = hipSuccess;
+    if (l->have_energy == 2) {
+        // chains per workgroup: as many as the LDS holds next to the partial sums, at most 8, no more than there are chains
+        int cb = 8;
+        while (cb > 1 && (cb / 2 >= l->n_chains || ((size_t)l->P * cb + (size_t)K3C_WAVES * cb * 64) * sizeof(float) > 150 * 1024)) cb /= 2;
+        for (int s = 0; s < n_steps && e == hipSuccess; ++s) {
+            float* tr = d_traj ? d_traj + (size_t)s * l->n_chains * l->pitch : nullptr;
+            const uint32_t st = step0 + (uint32_t)s;
+            if (cb == 8) e = k3c_launch<8>(l, l->x, l->x2, a, scale, seed, st, chain0, tr);
+            else if (cb == 4) e = k3c_launch<4>(l, l->x, l->x2, a, scale, seed, st, chain0, tr);
+            else if (cb == 2) e = k3c_launch<2>(l, l->x, l->x2, a, scale, seed, st, chain0, tr);
+            else e = k3c_launch<1>(l, l->x, l->x2, a, scale, seed, st, chain0, tr);
+            std::swap(l->x, l->x2);
+        }
+    } else {
+        int per = l->steps_per_launch > 0 ? l->steps_per_launch : n_steps;
+        for (int s = 0; s < n_steps; s += per) {
+            int ns = n_steps - s < per ? n_steps - s : per;
+            k3_langevin<<<grid, 256, 0, ctx->stream>>>(l->x, l->k, l->mu, l->n_chains, quads, l->pitch, ns, a, scale, (uint32_t)seed,
+                                                       (uint32_t)(seed >> 32), step0 + (uint32_t)s, chain0,
+                                                       d_traj ? d_traj + (size_t)s * l->n_chains * l->pitch : nullptr);
+        }
     }
-    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess && traj_host) {
         size_t w = (size_t)l->dim * sizeof(float);
         e = hipMemcpy2DAsync(traj_host, w, d_traj, (size_t)l->pitch * sizeof(float), w, (size_t)n_steps * l->n_chains,

@@ -14,6 +14,7 @@ from .core import (  # noqa: F401
     ConfigurationError,
     ProbabilisticNeuron,
     QuadraticEnergy,
+    QuadraticForm,
     SamplingError,
     ThermalSamplingUnit,
     TSUConfig,
@@ -32,7 +33,7 @@ from .models import (  # noqa: F401
 
 __all__ = [
     "ThermalSamplingUnit", "TSU", "TSUConfig", "ProbabilisticNeuron", "validate_distribution", "TSUError",
-    "ConfigurationError", "SamplingError", "QuadraticEnergy",
+    "ConfigurationError", "SamplingError", "QuadraticEnergy", "QuadraticForm",
     "GibbsSampler", "GibbsConfig", "HardwareEmulator",
     "IsingModel", "IsingChain", "IsingGrid", "IsingModel2D", "demonstrate_phase_transition",
 ]

@@ -104,6 +104,7 @@ SIGNATURES = {
     "tsu_langevin_set_state": (C.c_int, [_vp, _f32p]),
     "tsu_langevin_get_state": (C.c_int, [_vp, _f32p]),
     "tsu_langevin_set_energy": (C.c_int, [_vp, _f32p, _f32p]),
+    "tsu_langevin_set_coupling": (C.c_int, [_vp, _f32p, _f32p]),
     "tsu_langevin_restart": (C.c_int, [_vp, _f32p, C.c_float, C.c_uint64, C.c_uint32]),
     "tsu_langevin_step": (C.c_int, [_vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_uint32,
                                     C.c_uint32, _f32p]),
@@ -599,6 +600,12 @@ class LangevinChains:
         kk = np.ascontiguousarray(np.broadcast_to(np.asarray(k, dtype=np.float32), (self.dim,)))
         mm = np.ascontiguousarray(np.broadcast_to(np.asarray(mu, dtype=np.float32), (self.dim,)))
         self.ctx.check(self.lib.tsu_langevin_set_energy(self.h, _ptr(kk, _f32p), _ptr(mm, _f32p)))
+
+    def set_coupling(self, A, b=None):
+        """E = 1/2 x^T A x + b^T x with a symmetric (dim, dim) matrix: the steps that follow run the coupled kernel."""
+        aa = np.ascontiguousarray(A, dtype=np.float32).reshape(self.dim, self.dim)
+        bb = None if b is None else np.ascontiguousarray(np.broadcast_to(np.asarray(b, dtype=np.float32), (self.dim,)))
+        self.ctx.check(self.lib.tsu_langevin_set_coupling(self.h, _ptr(aa, _f32p), None if bb is None else _ptr(bb, _f32p)))
 
     def restart(self, x_init, amp, seed, chain0=0):
         xi = np.ascontiguousarray(np.broadcast_to(np.asarray(x_init, dtype=np.float32), (self.dim,)))

@@ -80,6 +80,27 @@ class QuadraticEnergy:
         return self.k * (np.asarray(x, dtype=np.float64) - self.mu)
 
 
+class QuadraticForm:
+    """Energy descriptor E(x) = 1/2 x^T A x + b^T x + c with a (dim, dim) matrix, callable like any reference energy_fn -- the
+    shape of the reference's multivariate callers (tsu/api.py:94).  Only the symmetric part of ``A`` enters the energy; it is
+    what the device keeps (gradient A_sym x + b: `csrc/langevin.hip` k3_coupled)."""
+
+    def __init__(self, A, b=0.0, c: float = 0.0):
+        A = np.asarray(A, dtype=np.float64)
+        if A.ndim != 2 or A.shape[0] != A.shape[1]:
+            raise ConfigurationError(f"QuadraticForm needs a square matrix, got shape {A.shape}")
+        self.A = 0.5 * (A + A.T)
+        self.b = np.broadcast_to(np.asarray(b, dtype=np.float64), (A.shape[0],)).copy()
+        self.c = float(c)
+
+    def __call__(self, x) -> float:
+        x = np.atleast_1d(np.asarray(x, dtype=np.float64))
+        return float(0.5 * x @ self.A @ x + self.b @ x + self.c)
+
+    def gradient(self, x) -> np.ndarray:
+        return self.A @ np.atleast_1d(np.asarray(x, dtype=np.float64)) + self.b
+
+
 _PROBE_FULL_MAX = 4096  # up to this dimension every coordinate is probed (2 d + 1 evaluations of O(d) work each)
 
 
@@ -95,6 +116,53 @@ def _verify_quadratic(energy_fn: Callable, cand: QuadraticEnergy, x0: np.ndarray
     return True
 
 
+_PROBE_COUPLED_MAX = 64  # up to this dimension a callable is also probed for a COUPLED quadratic (d (d + 1) / 2 + 2 d + 1 evaluations)
+
+
+def _recognise_coupled(energy_fn: Callable, x0: np.ndarray) -> Optional[QuadraticForm]:
+    """Fit E = 1/2 x^T A x + b^T x + c by second differences around x0 and verify it on random points (as `_verify_quadratic`)."""
+    d = x0.size
+    if d < 2 or d > _PROBE_COUPLED_MAX:
+        return None
+    try:
+        step = 0.5
+        e0 = float(energy_fn(x0.copy()))
+        ep, em = np.empty(d), np.empty(d)
+        for i in range(d):
+            xp, xm = x0.copy(), x0.copy()
+            xp[i] += step
+            xm[i] -= step
+            ep[i], em[i] = float(energy_fn(xp)), float(energy_fn(xm))
+        A = np.zeros((d, d))
+        A[np.arange(d), np.arange(d)] = (ep - 2 * e0 + em) / step ** 2
+        for i in range(d):
+            for j in range(i):
+                xpp = x0.copy()
+                xpp[i] += step
+                xpp[j] += step
+                A[i, j] = A[j, i] = (float(energy_fn(xpp)) - ep[i] - ep[j] + e0) / step ** 2
+        g0 = (ep - em) / (2 * step)  # gradient at x0 = A x0 + b
+        if not (np.all(np.isfinite(A)) and np.all(np.isfinite(g0))):
+            return None
+        # (couplings people write are short binary fractions: take the exact ones if they fit the rounding of the differences)
+        tol = 1e-9 * max(1.0, abs(e0)) / step ** 2
+        Ar = np.round(A * 1024) / 1024
+        if np.max(np.abs(Ar - A)) <= tol:
+            A = Ar
+        b = g0 - A @ x0
+        br = np.round(b * 1024) / 1024
+        if np.max(np.abs(br - b)) <= tol * max(1.0, float(np.max(np.abs(x0))) + 1.0):
+            b = br
+        c = e0 - float(0.5 * x0 @ A @ x0 + b @ x0)
+        cand = QuadraticForm(A, b, c)
+        # bounded below (a Langevin chain on an indefinite form runs away; the reference's loop would too, but slowly enough to return)
+        if np.min(np.linalg.eigvalsh(cand.A)) <= 0:
+            return None
+        return cand if _verify_quadratic(energy_fn, cand, x0) else None
+    except Exception:
+        return None
+
+
 def _recognise_quadratic(energy_fn: Callable, x_init: np.ndarray) -> Optional[QuadraticEnergy]:
     """Probe a callable, fit a separable quadratic and verify it on random points.  Returns None unless the fit is exact to
     ~1e-9 relative (so non-quadratic energies never take the GPU path).
@@ -103,7 +171,7 @@ def _recognise_quadratic(energy_fn: Callable, x_init: np.ndarray) -> Optional[Qu
     dim = 2**20): a bounded probe -- 64 random coordinates; if they agree on ONE stiffness and ONE centre, the uniform quadratic
     is verified on random points, in which all d coordinates move, so a single deviating coordinate fails the check.  About 140
     evaluations whatever d is.  Non-uniform separable quadratics of that size need a ``QuadraticEnergy`` descriptor."""
-    if isinstance(energy_fn, QuadraticEnergy):
+    if isinstance(energy_fn, (QuadraticEnergy, QuadraticForm)):
         return energy_fn
     x0 = np.atleast_1d(np.asarray(x_init, dtype=np.float64))
     d = x0.size
@@ -122,7 +190,7 @@ def _recognise_quadratic(energy_fn: Callable, x_init: np.ndarray) -> Optional[Qu
             kg = np.array([probe(i) for i in range(d)])
             k, g = kg[:, 0], kg[:, 1]
             if not np.all(np.isfinite(k)) or np.any(k <= 0):
-                return None
+                return _recognise_coupled(energy_fn, x0)
             mu = x0 - g / k
         else:
             idx = np.random.RandomState(54321).choice(d, size=64, replace=False)
@@ -148,9 +216,11 @@ def _recognise_quadratic(energy_fn: Callable, x_init: np.ndarray) -> Optional[Qu
         kf, mf = np.broadcast_to(k, (d,)), np.broadcast_to(mu, (d,))
         c = e0 - float(np.sum(0.5 * kf * (x0 - mf) ** 2))
         cand = QuadraticEnergy(k, mu, c)
-        return cand if _verify_quadratic(energy_fn, cand, x0) else None
+        if _verify_quadratic(energy_fn, cand, x0):
+            return cand
     except Exception:
-        return None
+        pass
+    return _recognise_coupled(energy_fn, x0)
 
 
 class ThermalSamplingUnit:
@@ -201,7 +271,12 @@ class ThermalSamplingUnit:
         self._call_counter += n_samples
         lc = _hip.LangevinChains(n_samples, d)
         try:
-            lc.set_energy(np.broadcast_to(q.k, (d,)).astype(np.float32), np.broadcast_to(q.mu, (d,)).astype(np.float32))
+            if isinstance(q, QuadraticForm):
+                if q.A.shape[0] != d:
+                    raise SamplingError(f"QuadraticForm of dimension {q.A.shape[0]} on a state of dimension {d}")
+                lc.set_coupling(q.A.astype(np.float32), q.b.astype(np.float32))
+            else:
+                lc.set_energy(np.broadcast_to(q.k, (d,)).astype(np.float32), np.broadcast_to(q.mu, (d,)).astype(np.float32))
             # sample 0 starts exactly at x_init; samples s > 0 at x_init + 0.1 * N(0,1)  (core.py:142-143)
             lc.restart(x0.astype(np.float32), 0.1, seed, chain0)
             if n_samples >= 1:
