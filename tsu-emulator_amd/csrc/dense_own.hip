@@ -32,7 +32,7 @@
                                 // OWN_RING superblocks, checked by the host)
 #define OWN_TAG_SPAN 16384u     // generation g of superblock number q carries tag q * SPAN + g + 1 (0 = never written)
 #define OWN_MAX_R 8
-#define OWN_SOLO_MAX 32           // toggle-list entries (before the workgroup's last row) a deciding wave gathers by itself
+#define OWN_SOLO_MAX 32           // toggle-list entries (before the workgroup's last row) a deciding wave gathers by itself (natural order; a caller's: 48)
 #ifndef OWN_REP_QUAD
 #define OWN_REP_QUAD 0          // replicas: 0 = one row per lane, scalar multipliers (own_axpy_rep); 1 = the quad layout in groups of four replicas
 #endif
@@ -58,7 +58,8 @@ struct OwnParams {
     int lmax;                    // toggle-list capacity (entries) = positions per superblock
     int rec_from, rec_every, resume, persist, refresh_off;
     int fail_at;                 // (tests) give up at this superblock number as if a wait had expired; < 0: never
-    int solo;                    // natural order, one replica, 64 rows per workgroup: short generations by the deciding wave alone
+    int solo;                    // one replica, 64 rows per workgroup: short generations by the deciding wave alone
+    int solo_max;                // ... lists of up to this many entries
     OwnRep rep[OWN_MAX_R];
 };
 
@@ -552,14 +553,179 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                 // handful of sites), the sum over its entry slots, the new correction -- with no workgroup barrier, no hand-over to a
                 // polling wave and no sixteen-wave reduction through LDS; the other fifteen waves wait at a barrier and are called in
                 // only for long lists (the first correction pass).  Commands through s_cmd: 1 = an axpy pass over lst, 2 = converged.
-                const bool solo = !ORD && R == 1 && M == 1 && P.solo;
+                // A caller's order: the same, with every workgroup active -- the wave polls all the groups (four per lane), every toggle
+                // goes to its rows twice (masked by position into the correction, unmasked into the running field).
+                const bool solo = R == 1 && M == 1 && P.solo;
                 if (solo && wv != 0) {
                     while (true) {
                         __syncthreads();  // (A) a command from wave 0
                         if (s_cmd != 1) break;
-                        OWN_AXPY_GEN(s_nlo, s_nle);
+                        if (ORD) own_axpy<TJ, M, R, 2, NA>(JT, n, lst, 0, s_nl, col0, myrow, pos, mypos, red, lane, wv);
+                        else OWN_AXPY_GEN(s_nlo, s_nle);
                         __syncthreads();  // (B) the partial sums are in red
                     }
+                } else if (solo && ORD) {
+                    // (the correction -- entries earlier in the order -- and the running field's change -- every entry -- stay in LDS, dC and
+                    // dA, and the polled masks go straight to LDS: registers are short here)
+                    while (true) {
+                        const unsigned tag = seq * OWN_TAG_SPAN + gi + 1u;
+                        unsigned long long* gbuf = P.gen + (size_t)(gi % OWN_NGEN) * G * 2;
+                        int v = vcur & 1;
+                        if (mine) {
+                            const double Tw = OWN_TW(0);
+                            v = own_decide(dF[OWN_AT(0)] + dC[OWN_AT(0)], dL[OWN_AT(0)], Tw, 1.0 / Tw, (uint32_t)site, (uint32_t)dpos, OWN_UNI(0), P.rep[0].sweep0 + (uint32_t)sw,
+                                           P.rep[0].tag, P.rep[0].k0, P.rep[0].k1);
+                        }
+                        vnew = v;
+                        const unsigned long long mk = __ballot(v != 0);
+                        if (lane < 2) st(gbuf + (size_t)mygroup * 2 + lane, ((mk >> (32 * lane)) & 0xFFFFFFFFull) | ((unsigned long long)tag << 32));
+                        // poll: lane l reads the granule pairs of groups 4 l .. 4 l + 3 until every pair carries this generation's tag
+                        {
+                            unsigned long long nw[4];
+                            const long long t0 = wall_clock64();
+                            bool failed = false;
+                            for (unsigned spins = 0;; ++spins) {
+                                bool all = true;
+#pragma unroll
+                                for (int g = 0; g < 4; ++g) {
+                                    const int k = 4 * lane + g;
+                                    const bool okk = k < np;
+                                    const unsigned long long* pp = gbuf + (size_t)(okk ? k : 0) * 2;
+                                    const unsigned long long lo = ld(pp), hi = ld(pp + 1);
+                                    all = all && (!okk || ((unsigned)(lo >> 32) == tag && (unsigned)(hi >> 32) == tag));
+                                    nw[g] = (lo & 0xFFFFFFFFull) | (hi << 32);
+                                }
+                                if (__ballot(!all) == 0ull) break;
+                                if ((spins & 63u) == 63u && (ld(&P.bar[BAR_ERR]) || wall_clock64() - t0 > CO_TIMEOUT)) {
+                                    st(&P.bar[BAR_ERR], 1u);
+                                    failed = true;
+                                    break;
+                                }
+                            }
+                            if (failed) {
+                                if (lane == 0) {
+                                    s_fail = 1;
+                                    s_cmd = 2;
+                                }
+                                __syncthreads();  // (A) releases the waiting waves
+                                return;
+                            }
+                            // nm <- the toggles, gm <- the new values (a toggled site is now 0 iff its bit in gm is 0)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const int k = 4 * lane + g;
+                                if (k < np) {
+                                    nm[k] = nw[g] ^ gm[k];
+                                    gm[k] = nw[g];
+                                }
+                            }
+                        }
+                        OWN_MARK(gi == 0 ? 9 : 1);
+                        // toggle list, ascending sites: four consecutive groups per lane, one prefix scan
+                        int pc = 0;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int k = 4 * lane + g;
+                            pc += k < np ? __popcll(nm[k]) : 0;
+                        }
+                        int off = pc;
+#pragma unroll
+                        for (int dd = 1; dd < 64; dd <<= 1) {
+                            const int x = __shfl_up(off, dd, 64);
+                            if (lane >= dd) off += x;
+                        }
+                        const int nl = __shfl(off, 63, 64);
+                        off -= pc;
+                        if (timing) {
+                            tl[4] += 1;
+                            tl[5] += (unsigned long long)nl;
+                        }
+                        if (nl == 0) break;  // nobody's value changed: the fixed point
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int k = 4 * lane + g;
+                            unsigned long long un = k < np ? nm[k] : 0ull;
+                            const unsigned long long val = k < np ? gm[k] : 0ull;
+                            while (un) {
+                                const int b = __ffsll((long long)un) - 1;
+                                un &= un - 1ull;
+                                lst[off++] = (uint32_t)(64 * k + b) | ((1u | (((val >> b) & 1ull) ? 0u : 2u)) << 16);
+                            }
+                        }
+                        if (nl <= P.solo_max) {
+                            __builtin_amdgcn_wave_barrier();
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the list is read back by other lanes of this wave)
+                            double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
+                            const int t = lane >> 4, nb = (nl + 3) >> 2;
+                            constexpr int SU = sizeof(TJ) == 4 ? 4 : 2;  // bundles in flight
+                            for (int b0 = 0; b0 < nb; b0 += SU) {
+                                OwnQuad<TJ> x[SU];
+                                uint32_t e[SU];
+#pragma unroll
+                                for (int u = 0; u < SU; ++u) {
+                                    const int k = (b0 + u) * 4 + t;
+                                    e[u] = k < nl ? lst[k] : 0u;
+                                }
+#pragma unroll
+                                for (int u = 0; u < SU; ++u)
+                                    if (b0 + u < nb) x[u].load(JT + (size_t)(e[u] & 0xFFFFu) * n + col0);
+#pragma unroll
+                                for (int u = 0; u < SU; ++u)
+                                    if (b0 + u < nb) {
+                                        const double sg = (double)(((int)(e[u] << 14)) >> 30);
+                                        const int pj = pos[e[u] & 0xFFFFu];
+#pragma unroll
+                                        for (int m = 0; m < 4; ++m) {
+                                            const double val = sg * x[u].get(m);
+                                            a1[m] += val;
+                                            a0[m] += pj < mypos[m] ? val : 0.0;
+                                        }
+                                    }
+                            }
+#pragma unroll
+                            for (int m = 0; m < 4; ++m) {
+                                a0[m] += __shfl_xor(a0[m], 16, 64);
+                                a0[m] += __shfl_xor(a0[m], 32, 64);
+                                a1[m] += __shfl_xor(a1[m], 16, 64);
+                                a1[m] += __shfl_xor(a1[m], 32, 64);
+                            }
+                            if (lane < 16) {
+#pragma unroll
+                                for (int m = 0; m < 4; ++m) {
+                                    red[4 * lane + m] = a0[m];
+                                    red[64 + 4 * lane + m] = a1[m];
+                                }
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            dC[OWN_AT(0)] += red[lane];
+                            dA[drow * 64 + lane] += red[64 + lane];
+                            __builtin_amdgcn_wave_barrier();
+                        } else {
+                            if (lane == 0) {
+                                s_nl = nl;
+                                s_cmd = 1;
+                            }
+                            __syncthreads();  // (A)
+                            own_axpy<TJ, M, R, 2, NA>(JT, n, lst, 0, nl, col0, myrow, pos, mypos, red, lane, wv);
+                            __syncthreads();  // (B)
+                            dC[OWN_AT(0)] += reduced(0);
+                            dA[drow * 64 + lane] += reduced(1);
+                        }
+                        OWN_MARK(gi == 0 ? 8 : 2);
+                        ++gi;
+                        if (gi + 2u >= OWN_TAG_SPAN) {
+                            if (lane == 0) {
+                                st(&P.bar[BAR_ERR + 2], 1u);
+                                s_fail = 1;
+                                s_cmd = 2;
+                            }
+                            __syncthreads();  // (A)
+                            return;
+                        }
+                    }
+                    if (lane == 0) s_cmd = 2;
+                    __syncthreads();  // (A) converged: everybody goes on
                 } else if (solo) {
                     const int kme = w - g_lo;  // my group's index among the polled ones (lane k <-> group g_lo + k)
                     double Cm = 0.0;  // (field and logit stay in LDS: registers are short here)
@@ -630,7 +796,7 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                                 lst[off++] = (uint32_t)(64 * g + b) | ((1u | (((nw >> b) & 1ull) ? 0u : 2u)) << 16);
                             }
                         }
-                        if (nle <= OWN_SOLO_MAX) {
+                        if (nle <= P.solo_max) {
                             // the short list by this wave alone: bundles of 4 entries, SU in flight per round, per-lane masks throughout
                             __builtin_amdgcn_wave_barrier();
                             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the list is read back by other lanes of this wave)
@@ -976,7 +1142,8 @@ int tsu_dense_own_run(tsu_dense* d, int R_real, const OwnRep* reps, int8_t* stat
     P.rec_from = rec_from;
     P.rec_every = rec_every > 0 ? rec_every : 1;
     P.fail_at = own_env("TSU_K2_OWN_TEST_FAIL", -1);
-    P.solo = own_env("TSU_K2_OWN_SOLO", 1) && NP <= 64;  // (one polled group per lane; the switch is read per call: A/B measurements)
+    P.solo_max = own_env("TSU_K2_OWN_SOLO_MAX", ord ? 48 : OWN_SOLO_MAX);  // (n = 16384: natural order flat from 16 to 32, a caller's order from 48 to 64)
+    P.solo = own_env("TSU_K2_OWN_SOLO", 1) && (ord ? NP <= 256 : NP <= 64);  // (one polled group per lane; the switch is read per call: A/B measurements)
     for (int r = 0; r < R; ++r) P.rep[r] = reps[r < R_real ? r : 0];  // (padding replicas repeat replica 0 on its own state copy: see the caller)
     static const int keep_fields = own_env("TSU_K2_KEEP_FIELDS", 1);
     const bool single = R_real == 1 && allow_persist;
