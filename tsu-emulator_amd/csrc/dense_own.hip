@@ -275,6 +275,8 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
     constexpr int PW = ND;               // the wave that polls and builds the lists (the first one that decides nothing)
     extern __shared__ unsigned long long own_lds[];
     __shared__ int s_nl, s_nlo, s_nle, s_cmd, s_fail;
+    __shared__ int s_nlr[2][OWN_MAX_R];  // (replicas) toggles per replica in the running generation (double-buffered by generation)
+    __shared__ unsigned s_long[3];       // (replicas) bit rho: replica rho's list of this generation needs all sixteen waves
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int w = (int)blockIdx.x, W = (int)gridDim.x, G = W * M;
     const int n = P.n;
@@ -291,6 +293,7 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
     double* dL = dC + R * M * 64;               //   logit of the uniform,
     double* dA = dL + R * M * 64;               //   (ORD) the running field's change inside the current superblock  [M][64]
     unsigned short* pos = (unsigned short*)(dA + M * 64);        // (ORD) [n] position of every site in this sweep's order
+    uint32_t* lsr = (uint32_t*)(dA + M * 64);                    // (replicas) [R][64] a replica's own short toggle list
 #define OWN_AT(rho) (((rho) * M + (R > 1 ? 0 : wv)) * 64 + lane)
 // the replicas a deciding wave handles: all of them (one replica), or its own (wave = replica)
 #define OWN_FOR_RHO(rho) for (int rho = (R > 1 ? wv : 0); rho < (R > 1 ? wv + 1 : 1); ++rho)
@@ -304,6 +307,7 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
     const bool site_ok = decider && site < n;
     const int mygroup = w * M + drow;
     if (threadIdx.x == 0) s_fail = 0;
+    if (threadIdx.x < 3) s_long[threadIdx.x] = 0u;
     // the axpy pass in the layout that suits the replica count (see own_axpy / own_axpy_rep)
 #define OWN_AXPY_ALL(nl_)                                                                                        \
     do {                                                                                                         \
@@ -416,25 +420,39 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
             s_nlo = 0;
         }
         for (int k = kb; k < ke; ++k) {
-            unsigned long long nw[R], tg[R], un = 0ull;
-#pragma unroll
-            for (int rho = 0; rho < R; ++rho) {
-                nw[rho] = newp[rho * sn + k];
-                tg[rho] = nw[rho] ^ (oldp ? oldp[rho * so + k] : 0ull);
-                un |= tg[rho];
-                if (write_back) oldp[rho * so + k] = nw[rho];
-            }
             const int g = g_lo + k;
             const int sbase = 64 * g;
             if (g == w * M) s_nlo = off;
-            while (un) {
-                const int b = __ffsll((long long)un) - 1;
-                un &= un - 1ull;
-                uint32_t code = 0u;
+            if (R == 1) {
+                const unsigned long long nw = newp[k], tg = nw ^ (oldp ? oldp[k] : 0ull);
+                if (write_back) oldp[k] = nw;
+                unsigned long long un = tg;
+                while (un) {
+                    const int b = __ffsll((long long)un) - 1;
+                    un &= un - 1ull;
+                    lst[off++] = (uint32_t)(sbase + b) | ((1u | (((nw >> b) & 1ull) ? 0u : 2u)) << 16);
+                }
+            } else {
+                // (several replicas: the masks are read from LDS again per entry rather than kept in 4 R registers -- this kernel is
+                // short of them; the old masks are written back after the entries are out)
+                unsigned long long un = 0ull;
 #pragma unroll
-                for (int rho = 0; rho < R; ++rho)
-                    if ((tg[rho] >> b) & 1ull) code |= (1u | (((nw[rho] >> b) & 1ull) ? 0u : 2u)) << (2 * rho);
-                lst[off++] = (uint32_t)(sbase + b) | (code << 16);
+                for (int rho = 0; rho < R; ++rho) un |= newp[rho * sn + k] ^ (oldp ? oldp[rho * so + k] : 0ull);
+                while (un) {
+                    const int b = __ffsll((long long)un) - 1;
+                    un &= un - 1ull;
+                    uint32_t code = 0u;
+#pragma unroll
+                    for (int rho = 0; rho < R; ++rho) {
+                        const unsigned long long nw = newp[rho * sn + k], tg = nw ^ (oldp ? oldp[rho * so + k] : 0ull);
+                        if ((tg >> b) & 1ull) code |= (1u | (((nw >> b) & 1ull) ? 0u : 2u)) << (2 * rho);
+                    }
+                    lst[off++] = (uint32_t)(sbase + b) | (code << 16);
+                }
+                if (write_back) {
+#pragma unroll
+                    for (int rho = 0; rho < R; ++rho) oldp[rho * so + k] = newp[rho * sn + k];
+                }
             }
             if (g == w * M + M - 1) s_nle = off;
         }
@@ -455,6 +473,182 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
             const unsigned want = (seq_now + 1u) * OWN_TAG_SPAN + 2u;
             const long long t0 = wall_clock64();
             while ((unsigned)(ld(p) >> 32) < want && wall_clock64() - t0 < 3000) __builtin_amdgcn_s_sleep(32);
+        }
+    };
+
+
+
+    // one replica's granules of groups [g_lo, g_lo + np), np <= 64, by wave rho = wv: lane k <-> group g_lo + k; the masks go to nm
+    auto poll_one = [&](const unsigned long long* buf, unsigned tag, int g_lo, int np, bool sleepy) {
+        const int rho = wv;
+        const bool okk = lane < np;
+        const unsigned long long* pp = buf + ((size_t)rho * G + g_lo + (okk ? lane : 0)) * 2;
+        const long long t0 = wall_clock64();
+        unsigned long long lo = 0ull, hi = 0ull;
+        for (unsigned spins = 0;; ++spins) {
+            lo = ld(pp);
+            hi = ld(pp + 1);
+            const bool all = !okk || ((unsigned)(lo >> 32) == tag && (unsigned)(hi >> 32) == tag);
+            if (__ballot(!all) == 0ull) break;
+            if (sleepy) __builtin_amdgcn_s_sleep(16);
+            if ((spins & 63u) == 63u && (ld(&P.bar[BAR_ERR]) || wall_clock64() - t0 > CO_TIMEOUT)) {
+                st(&P.bar[BAR_ERR], 1u);
+                s_fail = 1;
+                return;
+            }
+        }
+        if (okk) nm[rho * NP + lane] = (lo & 0xFFFFFFFFull) | (hi << 32);
+    };
+
+    // ---- replicas, generation by generation WITHOUT a polling wave: deciding wave rho handles replica rho's granules itself --------
+    // poll (lane k <-> group g_lo + k), toggle scan, and -- most generations move a handful of sites -- the row segments of a short list
+    // in the quad layout, added straight to `dst` (dC: masked, entries before my rows; dF: every entry).  Long lists are left to all
+    // sixteen waves: bit rho of s_long, toggles in nm, new values in gm (build_union below).  Eight pollers and eight list builders
+    // in parallel instead of one wave doing eight replicas' worth of both.
+    auto rep_step = [&](const unsigned long long* gbuf, unsigned tag, int g_lo, int np, unsigned gi, bool masked, double* dst) {
+        const int rho = wv;
+        const long long rp0 = (timing && gi > 0 && masked) ? wall_clock64() : 0;
+        unsigned long long nw = 0ull;
+        {
+            const bool okk = lane < np;
+            const unsigned long long* pp = gbuf + ((size_t)rho * G + g_lo + (okk ? lane : 0)) * 2;
+            const long long t0 = wall_clock64();
+            for (unsigned spins = 0;; ++spins) {
+                const unsigned long long lo = ld(pp), hi = ld(pp + 1);
+                const unsigned tl_ = (unsigned)(lo >> 32), th_ = (unsigned)(hi >> 32);
+                const bool all = !okk || (tl_ == tag && th_ == tag);
+                nw = (lo & 0xFFFFFFFFull) | (hi << 32);
+                if (__ballot(okk && (tl_ > tag || th_ > tag)) != 0ull) {  // (a follower a whole ring behind: tags only grow in a buffer)
+                    st(&P.bar[BAR_ERR], 1u);
+                    s_fail = 1;
+                    return;
+                }
+                if (__ballot(!all) == 0ull) break;
+                if ((spins & 63u) == 63u && (ld(&P.bar[BAR_ERR]) || wall_clock64() - t0 > CO_TIMEOUT)) {
+                    st(&P.bar[BAR_ERR], 1u);
+                    s_fail = 1;
+                    return;
+                }
+            }
+        }
+        const bool rtiming = timing && gi > 0 && masked;  // (wave 0 of the last workgroup: its own polling and what follows it)
+        const long long rp1 = rtiming ? wall_clock64() : 0;
+        if (rtiming) tl[10] += (unsigned long long)(rp1 - rp0);
+        unsigned long long tg = 0ull;
+        if (lane < np) {
+            tg = nw ^ gm[rho * NP + lane];
+            gm[rho * NP + lane] = nw;
+            nm[rho * NP + lane] = tg;
+        }
+        const int pc = __popcll(tg);
+        int off = pc;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const int x = __shfl_up(off, dd, 64);
+            if (lane >= dd) off += x;
+        }
+        const int nl = __shfl(off, 63, 64);
+        off -= pc;
+        const int kme = w - g_lo;  // (M = 1: my group among the polled ones; a follower's lies outside: everything counts)
+        const int cnt = masked ? __shfl(off + pc, kme, 64) : nl;
+        if (lane == 0) s_nlr[gi & 1u][rho] = nl;
+        if (cnt == 0) return;
+        if (cnt > P.solo_max) {
+            if (lane == 0) atomicOr(&s_long[gi % 3u], 1u << rho);
+            return;
+        }
+        uint32_t* mylst = lsr + rho * 64;
+        if (off < cnt) {
+            unsigned long long un = tg;
+            const int g = g_lo + lane;
+            while (un) {
+                const int b = __ffsll((long long)un) - 1;
+                un &= un - 1ull;
+                mylst[off++] = (uint32_t)(64 * g + b) | ((1u | (((nw >> b) & 1ull) ? 0u : 2u)) << 16);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the list is read back by other lanes of this wave)
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        const int t = lane >> 4, nb = (cnt + 3) >> 2;
+        constexpr int SU = sizeof(TJ) == 4 ? 4 : 2;  // bundles in flight
+        for (int b0 = 0; b0 < nb; b0 += SU) {
+            OwnQuad<TJ> x[SU];
+            uint32_t e[SU];
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int k = (b0 + u) * 4 + t;
+                e[u] = k < cnt ? mylst[k] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < SU; ++u)
+                if (b0 + u < nb) x[u].load(JT + (size_t)(e[u] & 0xFFFFu) * n + col0);
+#pragma unroll
+            for (int u = 0; u < SU; ++u)
+                if (b0 + u < nb) {
+                    const int j = (int)(e[u] & 0xFFFFu);
+                    const double sg = (double)(((int)(e[u] << 14)) >> 30);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc[m] += (!masked || j < myrow + m) ? sg * x[u].get(m) : 0.0;
+                }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            acc[m] += __shfl_xor(acc[m], 16, 64);
+            acc[m] += __shfl_xor(acc[m], 32, 64);
+        }
+        double* myred = red + (size_t)wv * NA * RW;  // (this wave's own part of the partial-sum area)
+        if (lane < 16) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) myred[4 * lane + m] = acc[m];
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        dst[OWN_AT(rho)] += myred[lane];
+        __builtin_amdgcn_wave_barrier();
+        if (rtiming) tl[11] += (unsigned long long)(wall_clock64() - rp1);
+    };
+    // The union list of the replicas in `lm`, built by ALL sixteen waves (np <= 64 groups): toggles in tgp[rho * NP + k], new values in
+    // vp[rho * NP + k].  Every wave computes the groups' offsets (lane k <-> group k, one prefix scan), then takes the groups wv, wv + 16,
+    // ...: lane b = site b of the group, its entry goes to offset + (toggled sites below it).  (One wave building the first
+    // generation's ~4000 entries, 8 replicas' codes each, took 40 us.)
+    auto build_par = [&](const unsigned long long* tgp, int ts, const unsigned long long* vp, int vs, unsigned lm, int g_lo, int np) {
+        unsigned long long un = 0ull;
+        if (lane < np) {
+#pragma unroll
+            for (int rho = 0; rho < R; ++rho)
+                if ((lm >> rho) & 1u) un |= tgp[rho * ts + lane];
+        }
+        const int pc = __popcll(un);
+        int off = pc;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const int x = __shfl_up(off, dd, 64);
+            if (lane >= dd) off += x;
+        }
+        const int total = __shfl(off, 63, 64);
+        off -= pc;
+        if (wv == 0) {
+            const int kme = w * M - g_lo;  // (M = 1) my group among these, if it is one of them
+            const int nlo = (kme >= 0 && kme < np) ? __shfl(off, kme, 64) : 0;
+            const int nle = (kme >= 0 && kme < np) ? __shfl(off + pc, kme, 64) : 0;
+            if (lane == 0) {
+                s_nl = total;
+                s_nlo = nlo;
+                s_nle = nle;
+            }
+        }
+        for (int k = wv; k < np; k += OWN_WAVES) {
+            const unsigned long long ug = __shfl(un, k, 64);  // (wave-uniform)
+            if (ug == 0ull) continue;
+            const int og = __shfl(off, k, 64);
+            if ((ug >> lane) & 1ull) {
+                uint32_t code = 0u;
+#pragma unroll
+                for (int rho = 0; rho < R; ++rho)
+                    if (((lm >> rho) & 1u) && ((tgp[rho * ts + k] >> lane) & 1ull)) code |= (1u | (((vp[rho * vs + k] >> lane) & 1ull) ? 0u : 2u)) << (2 * rho);
+                lst[og + __popcll(ug & ((1ull << lane) - 1ull))] = (uint32_t)(64 * (g_lo + k) + lane) | (code << 16);
+            }
         }
     };
 
@@ -505,7 +699,11 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                 const int lch = LMAX / 64;  // groups per list
                 for (int g0 = 0; g0 < G; g0 += lch) {
                     const int np = G - g0 < lch ? G - g0 : lch;
-                    if (wv == PW) build_list(vmask + g0, G, nullptr, 0, g0, np, false);
+                    if constexpr (R > 1) {
+                        build_par(vmask + g0, G, vmask + g0, G, (1u << R) - 1u, g0, np);  // (every set bit: a toggle from 0 to 1)
+                    } else {
+                        if (wv == PW) build_list(vmask + g0, G, nullptr, 0, g0, np, false);
+                    }
                     __syncthreads();
                     const int nl = s_nl;
                     OWN_AXPY_ALL(nl);
@@ -865,7 +1063,54 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                     __syncthreads();  // (A) converged: everybody goes on
                 }
                 if (solo && s_fail) return;
-                while (!solo) {
+                constexpr bool rsolo = R > 1;  // (replicas: always by rep_step; the host keeps their superblocks at <= 64 groups)
+                while (rsolo) {
+                    const unsigned tag = seq * OWN_TAG_SPAN + gi + 1u;
+                    unsigned long long* gbuf = P.gen + (size_t)(gi % OWN_NGEN) * R * G * 2;
+                    if (decider) {
+                        OWN_FOR_RHO(rho) {
+                            int v = (vcur >> rho) & 1;
+                            if (mine) {
+                                const double Tw = OWN_TW(rho);
+                                v = own_decide(dF[OWN_AT(rho)] + dC[OWN_AT(rho)], dL[OWN_AT(rho)], Tw, 1.0 / Tw, (uint32_t)site, (uint32_t)dpos, OWN_UNI(rho),
+                                               P.rep[rho].sweep0 + (uint32_t)sw, P.rep[rho].tag, P.rep[rho].k0, P.rep[rho].k1);
+                            }
+                            vnew = (vnew & ~(1 << rho)) | (v << rho);
+                            const unsigned long long mk = __ballot(v != 0);
+                            if (lane < 2)
+                                st(gbuf + ((size_t)rho * G + mygroup) * 2 + lane, ((mk >> (32 * lane)) & 0xFFFFFFFFull) | ((unsigned long long)tag << 32));
+                        }
+                        rep_step(gbuf, tag, g_lo, np, gi, true, dC);
+                    }
+                    __syncthreads();  // (A) every replica's count and list (or its bit in s_long) is there
+                    if (s_fail) return;
+                    if (threadIdx.x == 0) s_long[(gi + 2u) % 3u] = 0u;
+                    int total = 0;
+#pragma unroll
+                    for (int rho = 0; rho < R; ++rho) total += s_nlr[gi & 1u][rho];
+                    OWN_MARK(gi == 0 ? 9 : 1);
+                    if (timing) {
+                        tl[4] += 1;
+                        tl[5] += (unsigned long long)total;
+                    }
+                    if (total == 0) break;  // nobody's value changed in any replica: the fixed point
+                    const unsigned lm = s_long[gi % 3u];
+                    if (lm) {
+                        build_par(nm, NP, gm, NP, lm, g_lo, np);
+                        __syncthreads();
+                        OWN_AXPY_GEN(s_nlo, s_nle);
+                        __syncthreads();
+                        if (decider && ((lm >> wv) & 1u)) dC[OWN_AT(wv)] += reduced(wv);
+                        __syncthreads();  // (red is rewritten by the next generation's solo passes)
+                    }
+                    OWN_MARK(gi == 0 ? 8 : 2);
+                    ++gi;
+                    if (gi + 2u >= OWN_TAG_SPAN) {
+                        if (threadIdx.x == 0) st(&P.bar[BAR_ERR + 2], 1u);
+                        return;
+                    }
+                }
+                if constexpr (R == 1) while (!solo) {
                     const unsigned tag = seq * OWN_TAG_SPAN + gi + 1u;
                     unsigned long long* gbuf = P.gen + (size_t)(gi % OWN_NGEN) * R * G * 2;
                     if (decider) {
@@ -977,7 +1222,28 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                         gm[rho * NP + k] = vmask[rho * G + g_lo + k];
                     }
                     __syncthreads();
-                    for (unsigned gi = 0;; ++gi) {
+                    constexpr bool rsolo = R > 1;
+                    for (unsigned gi = 0; rsolo; ++gi) {
+                        if (decider) rep_step(P.gen + (size_t)(gi % OWN_NGEN) * R * G * 2, seq * OWN_TAG_SPAN + gi + 1u, g_lo, np, gi, false, dF);
+                        __syncthreads();  // (A)
+                        if (s_fail) return;
+                        if (threadIdx.x == 0) s_long[(gi + 2u) % 3u] = 0u;
+                        int total = 0;
+#pragma unroll
+                        for (int rho = 0; rho < R; ++rho) total += s_nlr[gi & 1u][rho];
+                        if (total == 0) break;
+                        const unsigned lm = s_long[gi % 3u];
+                        if (lm) {
+                            build_par(nm, NP, gm, NP, lm, g_lo, np);
+                            __syncthreads();
+                            OWN_AXPY_ALL(s_nl);
+                            __syncthreads();
+                            if (decider && ((lm >> wv) & 1u)) dF[OWN_AT(wv)] += reduced(wv);
+                            __syncthreads();
+                        }
+                        if (gi + 3u >= OWN_TAG_SPAN) return;  // (the deciders have failed the call)
+                    }
+                    if constexpr (R == 1) for (unsigned gi = 0;; ++gi) {
                         if (wv == PW) {
                             poll(P.gen + (size_t)(gi % OWN_NGEN) * R * G * 2, seq * OWN_TAG_SPAN + gi + 1u, g_lo, np, false);
                             build_list(nm, NP, gm, NP, g_lo, np, true);
@@ -1003,10 +1269,26 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
                 } else {
                     // not my superblock, nor the one before mine: wait for its final values, apply the flips to my rows
                     OWN_MARK(0);
-                    if (wv == PW) {
-                        poll(P.fin + (size_t)slot * R * G * 2, seq + 1u, g_lo, np, true);
-                        build_list(nm, NP, vmask + g_lo, G, g_lo, np, true);
-                        yield_to_next(seq, sb, sw);
+                    if constexpr (R > 1) {
+                        // (eight waves poll a replica's final masks each; then one builds the union list)
+                        if (wv < R) {
+                            poll_one(P.fin + (size_t)slot * R * G * 2, seq + 1u, g_lo, np, true);
+                            if (lane < np) {  // toggles against the committed values (gm is free here); the new values are committed
+                                const unsigned long long nv = nm[wv * NP + lane];
+                                gm[wv * NP + lane] = nv ^ vmask[wv * G + g_lo + lane];
+                                vmask[wv * G + g_lo + lane] = nv;
+                            }
+                        }
+                        __syncthreads();
+                        if (s_fail) return;
+                        build_par(gm, NP, nm, NP, (1u << R) - 1u, g_lo, np);
+                        if (wv == PW) yield_to_next(seq, sb, sw);
+                    } else {
+                        if (wv == PW) {
+                            poll(P.fin + (size_t)slot * R * G * 2, seq + 1u, g_lo, np, true);
+                            build_list(nm, NP, vmask + g_lo, G, g_lo, np, true);
+                            yield_to_next(seq, sb, sw);
+                        }
                     }
                     __syncthreads();
                     if (s_fail) return;
@@ -1085,6 +1367,7 @@ int tsu_dense_own_run(tsu_dense* d, int R_real, const OwnRep* reps, int8_t* stat
     const int cands[3] = {16384, 8192, 4096};
     for (int ci = sb_env > 0 ? 2 : (ord ? 0 : 2); ci < 3; ++ci) {
         sb = sb_env > 0 ? sb_env : cands[ci];
+        if (R > 1 && sb > 4096) sb = 4096;  // (replicas: a deciding wave polls one group per lane)
         if (sb < RW) sb = RW;
         if (sb > 16384) sb = 16384;
         sbw = sb / RW;
@@ -1093,7 +1376,7 @@ int tsu_dense_own_run(tsu_dense* d, int R_real, const OwnRep* reps, int8_t* stat
         nsb = ord ? (n + sbw * RW - 1) / (sbw * RW) : (W + sbw - 1) / sbw;
         NP = ord ? G : sbw * M;
         lds_bytes = ((size_t)8 * (R * G + 2 * R * NP) + (size_t)8 * OWN_WAVES * NA * M * 64 + (size_t)4 * lmax + (size_t)8 * (3 * R + 1) * M * 64 +
-                     (ord ? (size_t)2 * n : 0) + 15) / 16 * 16;
+                     (ord ? (size_t)2 * n : (R > 1 ? (size_t)R * 64 * 4 : 0)) + 15) / 16 * 16;
         if (lds_bytes <= 150 * 1024) break;
     }
     if (!ord && nsb > OWN_RING) return TSU_OK;
@@ -1142,8 +1425,10 @@ int tsu_dense_own_run(tsu_dense* d, int R_real, const OwnRep* reps, int8_t* stat
     P.rec_from = rec_from;
     P.rec_every = rec_every > 0 ? rec_every : 1;
     P.fail_at = own_env("TSU_K2_OWN_TEST_FAIL", -1);
-    P.solo_max = own_env("TSU_K2_OWN_SOLO_MAX", ord ? 48 : OWN_SOLO_MAX);  // (n = 16384: natural order flat from 16 to 32, a caller's order from 48 to 64)
-    P.solo = own_env("TSU_K2_OWN_SOLO", 1) && (ord ? NP <= 256 : NP <= 64);  // (one polled group per lane; the switch is read per call: A/B measurements)
+    P.solo_max = own_env("TSU_K2_OWN_SOLO_MAX", (ord || R > 1) ? 48 : OWN_SOLO_MAX);
+    if (P.solo_max > 64) P.solo_max = 64;  // (a replica's own short list has 64 slots)
+    if (P.solo_max < 0) P.solo_max = 0;  // (n = 16384: natural order flat from 16 to 32, a caller's order from 48 to 64)
+    P.solo = own_env("TSU_K2_OWN_SOLO", 1) && (ord ? NP <= 256 : NP <= 64) && (R == 1 || M == 1);  // (one polled group per lane; the switch is read per call: A/B measurements)
     for (int r = 0; r < R; ++r) P.rep[r] = reps[r < R_real ? r : 0];  // (padding replicas repeat replica 0 on its own state copy: see the caller)
     static const int keep_fields = own_env("TSU_K2_KEEP_FIELDS", 1);
     const bool single = R_real == 1 && allow_persist;
