@@ -134,6 +134,36 @@ def test_replica_batch_every_replica_is_its_own_single_chain(n, R):
     d.close()
 
 
+@pytest.mark.parametrize("n,R", [(2304, 3), (4100, 8)])
+def test_replica_fields_are_kept_from_call_to_call(n, R):
+    """A tempering loop: short calls on states that come back unchanged, swapped among themselves, or edited.  The replicas' fields
+    stay on the device (dense.h rep_fields): a state that returns byte for byte resumes from its fields wherever it now sits, an
+    edited one makes the call start from scratch -- every call's result is the oracle's, replica by replica."""
+    J, b, _ = _system(n, 5 * n, False)
+    J64 = J.astype(np.float64)
+    rng = np.random.default_rng(n)
+    sts = rng.integers(0, 2, size=(R, n)).astype(np.int8)
+    temps = [0.8 + 0.2 * r for r in range(R)]
+    d = _dense(J, b, False)
+    sweep0 = 0
+    for call in range(6):
+        if call == 2:  # neighbours swap (as a tempering exchange does)
+            sts[[0, 1]] = sts[[1, 0]]
+        if call == 3:  # a rotation of all of them
+            sts = np.roll(sts, 1, axis=0)
+        if call == 4:  # one state is edited by the caller: nothing may be taken over for it
+            sts[R - 1, 7] ^= 1
+        k = 1 if call % 2 else 2
+        out = d.sweep_replicas(sts, temps, k, [3] * R, [sweep0] * R, replicas=list(range(R)))
+        for r in range(R):
+            want = ora.dense_sweep_philox(sts[r], J64, b, temps[r], k, 3, sweep0=sweep0, replica=r)
+            np.testing.assert_array_equal(out[r], want, err_msg=f"call {call}, replica {r}")
+        sts = out
+        sweep0 += k
+    assert d.launch_counts()[0] == 6
+    d.close()
+
+
 def test_replica_batch_of_eleven_and_replayed_uniforms():
     # eleven replicas = a launch of eight and one of three (padded to four); replayed uniforms per replica
     n, R, k = 2560, 11, 2

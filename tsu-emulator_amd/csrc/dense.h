@@ -39,6 +39,13 @@ struct tsu_dense {
     size_t temps_cap;
     void* rep_buf;      // tsu_dense_sweep_replicas: states, replayed uniforms and per-replica parameters
     size_t rep_cap;
+    // k2_own hands the REPLICAS' fields from call to call as well (a tempering loop is a loop of short calls on states that come back
+    // unchanged or swapped among themselves: without this every call pays a full pass over J for all replicas):
+    double* rep_fields[2];  // [8][n] each: the fields of the states the last replica call returned (in rep_cur), and where the next writes
+    int8_t* rep_prev;       // host copy of those states [8][n]: an incoming state is matched against them byte for byte
+    int rep_prev_n;         // how many there are (0: none)
+    int rep_cur;
+    int rep_since;          // sweeps since the replicas' fields were last computed from scratch
     int co_disabled;    // cooperative launch unavailable or failed once: use the multi-launch path
     unsigned long long* pp_masks;  // k2_pipe: flip-mask granules of the solver teams
     int pp_failed;      // k2_pipe ran and left the state half updated: the caller restores it, later calls skip the pipeline
@@ -59,6 +66,7 @@ struct tsu_dense {
 struct OwnRep {
     double T;
     uint32_t sweep0, tag, k0, k1;
+    int src;  // (several replicas, fields kept) which of the previous call's replicas this state is: row of its fields
 };
 
 

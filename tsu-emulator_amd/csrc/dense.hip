@@ -875,6 +875,9 @@ int tsu_dense_destroy(tsu_dense* d) {
     if (d->samples) (void)hipFree(d->samples);
     if (d->temps) (void)hipFree(d->temps);
     if (d->rep_buf) (void)hipFree(d->rep_buf);
+    if (d->rep_fields[0]) (void)hipFree(d->rep_fields[0]);
+    if (d->rep_fields[1]) (void)hipFree(d->rep_fields[1]);
+    free(d->rep_prev);
     if (d->co_logit) (void)hipFree(d->co_logit);
     if (d->co_corr) (void)hipFree(d->co_corr);
     if (d->co_d0) (void)hipFree(d->co_d0);
@@ -1231,9 +1234,35 @@ int tsu_dense_sweep_replicas(tsu_dense* d, int n_replicas, const double* tempera
             }
             int8_t* ds = (int8_t*)d->rep_buf;
             double* du = ub_ ? (double*)((char*)d->rep_buf + ((sb_ + 7) / 8) * 8) : nullptr;
+            // one group of replicas: their fields stay on the device from call to call; a state that comes back byte for byte as one
+            // of those the last call returned (in any position: tempering swaps them) resumes from that state's fields
+            const bool keep = n_replicas <= 8;
+            if (keep && !d->rep_prev) {
+                d->rep_prev = (int8_t*)malloc((size_t)8 * n);
+                if (d->rep_prev && hipMalloc(&d->rep_fields[0], (size_t)8 * n * sizeof(double)) == hipSuccess &&
+                    hipMalloc(&d->rep_fields[1], (size_t)8 * n * sizeof(double)) == hipSuccess) {
+                    d->rep_prev_n = 0;
+                } else {
+                    if (d->rep_fields[0]) (void)hipFree(d->rep_fields[0]);
+                    if (d->rep_fields[1]) (void)hipFree(d->rep_fields[1]);
+                    d->rep_fields[0] = d->rep_fields[1] = nullptr;
+                    free(d->rep_prev);
+                    d->rep_prev = nullptr;
+                    (void)hipGetLastError();
+                }
+            }
+            const bool can_keep = keep && d->rep_prev && d->rep_fields[1];
+            bool all_known = can_keep && d->rep_prev_n > 0;
             OwnRep reps[8];
             for (int q = 0; q < mp; ++q) {
                 const int r = r0 + (q < m ? q : 0);
+                reps[q].src = -1;
+                if (can_keep)
+                    for (int t = 0; t < d->rep_prev_n && reps[q].src < 0; ++t) {
+                        const int p = (q + t) % d->rep_prev_n;  // (its own position first)
+                        if (memcmp(states_host + (size_t)r * n, d->rep_prev + (size_t)p * n, (size_t)n) == 0) reps[q].src = p;
+                    }
+                all_known = all_known && reps[q].src >= 0;
                 reps[q].T = temperatures[r];
                 reps[q].sweep0 = sweep0s[r];
                 reps[q].tag = TSU_TAG_DENSE | (replicas[r] << 8);
@@ -1245,15 +1274,23 @@ int tsu_dense_sweep_replicas(tsu_dense* d, int n_replicas, const double* tempera
                                                     hipMemcpyHostToDevice, ctx->stream));
             }
             int done = 0;
-            const int rc = tsu_dense_own_run(d, mp, reps, ds, n_sweeps, du, nullptr, nullptr, nullptr, 0, 1, false, false, &done);
-            if (rc != TSU_OK) return rc;
+            const int rc = tsu_dense_own_run(d, mp, reps, ds, n_sweeps, du, nullptr, nullptr, nullptr, 0, 1, all_known, can_keep, &done);
+            if (rc != TSU_OK) {
+                d->rep_prev_n = 0;
+                return rc;
+            }
             if (!done) {
                 d->own_failed = 0;  // (the replicas' states live in a scratch buffer: nothing of the system was touched)
+                d->rep_prev_n = 0;
                 all_done = false;
                 break;
             }
             TSU_HIP_TRY(ctx, hipMemcpyAsync(states_host + (size_t)r0 * n, ds, (size_t)m * n, hipMemcpyDeviceToHost, ctx->stream));
             TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (can_keep) {
+                memcpy(d->rep_prev, states_host + (size_t)r0 * n, (size_t)m * n);
+                d->rep_prev_n = m;
+            }
             r_done = r0 + m;
         }
         if (all_done) return TSU_OK;

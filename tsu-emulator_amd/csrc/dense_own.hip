@@ -51,7 +51,8 @@ struct OwnParams {
     const int64_t* order;        // [n_sweeps][n] visiting orders, or nullptr (natural order)
     const double* temps;         // one temperature per sweep (R == 1), or nullptr
     int8_t* samples;             // (R == 1) the state after sweep rec_from + m rec_every goes to samples + (m - 1) n, or nullptr
-    double* fields_all;          // (R == 1) [n] fields kept from call to call (dense.h)
+    double* fields_all;          // [R][n] fields kept from call to call (dense.h): read at the start of a resumed call (row rep[rho].src) ...
+    double* fields_out;          // ... written at the end of a call that keeps them (several replicas: another buffer -- the rows change places)
     unsigned long long* timeline;
     int n, n_sweeps;
     int sbw;                     // workgroups per superblock (natural order); positions per superblock = sbw * 64 M
@@ -691,7 +692,11 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
         const bool start_phase = sw == 0 || ((sw + P.refresh_off) % CO_REFRESH) == 0;
         if (start_phase) {
             if (sw == 0 && P.resume) {
-                if (site_ok) dF[OWN_AT(0)] = P.fields_all[site];
+                if (decider) {
+                    OWN_FOR_RHO(rho) {
+                        if (site_ok) dF[OWN_AT(rho)] = P.fields_all[(size_t)(R > 1 ? P.rep[rho].src : 0) * n + site];
+                    }
+                }
             } else {
                 if (decider) {
                     OWN_FOR_RHO(rho) dF[OWN_AT(rho)] = (site_ok && P.bias) ? P.bias[site] : 0.0;
@@ -1305,7 +1310,11 @@ __global__ __launch_bounds__(OWN_THREADS) void k2_own(OwnParams P) {
             }
         }
     }
-    if (P.persist && site_ok) P.fields_all[site] = dF[OWN_AT(0)];
+    if (P.persist && decider) {
+        OWN_FOR_RHO(rho) {
+            if (site_ok) P.fields_out[(size_t)rho * n + site] = dF[OWN_AT(rho)];
+        }
+    }
     if (timing)
         for (int x = 0; x < 12; ++x) P.timeline[x] = tl[x];
 #undef OWN_MARK
@@ -1417,7 +1426,8 @@ int tsu_dense_own_run(tsu_dense* d, int R_real, const OwnRep* reps, int8_t* stat
     P.order = order_dev;
     P.temps = temps_dev;
     P.samples = samples_dev;
-    P.fields_all = d->co_fields;
+    P.fields_all = R_real > 1 ? d->rep_fields[d->rep_cur] : d->co_fields;
+    P.fields_out = R_real > 1 ? d->rep_fields[d->rep_cur ^ 1] : d->co_fields;
     P.n = n;
     P.n_sweeps = n_sweeps;
     P.sbw = sbw;
@@ -1435,6 +1445,12 @@ int tsu_dense_own_run(tsu_dense* d, int R_real, const OwnRep* reps, int8_t* stat
     P.resume = single && keep_fields && fields_were_valid && (d->since_refresh % CO_REFRESH) != 0 ? 1 : 0;
     P.refresh_off = P.resume ? d->since_refresh : 0;
     P.persist = single && keep_fields && d->pipe_streak >= 1 ? 1 : 0;
+    if (R_real > 1) {  // (replicas: the caller matched the incoming states with the ones whose fields are kept: rep[].src)
+        const bool rk = allow_persist && keep_fields && d->rep_fields[0] && d->rep_fields[1];
+        P.resume = rk && fields_were_valid && (d->rep_since % CO_REFRESH) != 0 ? 1 : 0;
+        P.refresh_off = P.resume ? d->rep_since : 0;
+        P.persist = rk ? 1 : 0;
+    }
     static const int verbose = own_env("TSU_K2_VERBOSE", 0);
     unsigned long long* d_tl = nullptr;
     if (verbose >= 2) {
@@ -1476,6 +1492,10 @@ int tsu_dense_own_run(tsu_dense* d, int R_real, const OwnRep* reps, int8_t* stat
     }
     *done = 1;
     d->n_own += 1;
+    if (R_real > 1 && P.persist) {
+        d->rep_since = (P.refresh_off + n_sweeps) % CO_REFRESH;
+        d->rep_cur ^= 1;
+    }
     if (R_real == 1 && allow_persist) {
         d->since_refresh = (P.refresh_off + n_sweeps) % CO_REFRESH;
         d->fields_valid = P.persist;
