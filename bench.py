@@ -224,9 +224,10 @@ def time_langevin(hip, ctx, counters):
     gbs = 4.0 * d2 * d2 * steps / (ms * 1e-3) / 1e9
     out["coupled_quadratic_d16384_one_chain"] = {
         "us_per_step": ms * 1e3 / steps, "element_steps_per_s": d2 * steps / (ms * 1e-3), "variance": var,
-        "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+        "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                     "traffic": counters.get("k3_coupled_d16384_one_chain", {}).get("hbm_bytes"),
                      "note": "k3_coupled, one launch per step: algorithmic d^2 x 4 B per step (the symmetric matrix streamed once, gradient "
-                             "A x + b as an axpy over its rows); best of 3 calls of 30 steps; traffic: not collected"}}
+                             "A x + b as an axpy over its rows); best of 3 calls of 30 steps; traffic: PMC bytes per launch"}}
     return out
 
 
@@ -360,13 +361,15 @@ def time_sparse_chain(hip, ctx, counters, n=1 << 24):
     gbs = alg * n / (ms * 1e-3) / 1e9
     return {"sites": n, "ms_per_sweep": ms, "spin_updates_per_s": n / (ms * 1e-3),
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "traffic": None,
+                         "traffic": ((counters.get("k5_stencil4_first_class_2p23", {}).get("hbm_bytes") or 0) +
+                                     (counters.get("k5_stencil4_second_class_2p23", {}).get("hbm_bytes") or 0)) or None,
+                         "valu_lane_instructions_per_update_first_class": ((counters.get("k5_stencil4_first_class_2p23", {}).get("valu_insts") or 0) * 64.0 / (n / 2)) or None,
                          "note": "regular, paired colour classes (k5_stencil4<1> + <2>): algorithmic 4 B per update = 34 MB per launch of one "
                                  "colour class (2^23 sites), so the sweep is bound by instruction issue -- ONE Philox block per PAIR of sites "
                                  "(20 64-bit multiply-adds, ~17 us per 2^23 blocks), computed by the first class's launch, which also prepares "
                                  "the second class's decisions by neighbour count; the second launch is a 4.4 TB/s byte shuffle (7.7 us) -- "
                                  "not by HBM; the round-2 CSR kernel moved 43 B per update (0.52 of the roofline at 9.6e10 updates/s); "
-                                 "traffic: not collected for this kernel"},
+                                 "traffic: PMC bytes of the two launches of a sweep (the read half a lower estimate: 4 B/lane loads)"},
             "M": m / n}
 
 
