@@ -164,6 +164,29 @@ def test_replica_fields_are_kept_from_call_to_call(n, R):
     d.close()
 
 
+def test_energy_of_a_replica_state_comes_from_its_kept_fields():
+    """parallel_tempering asks for every replica's energy between its sweeps (gibbs.py:303-323): set_state + energy of a state the
+    last replica call returned takes that state's kept fields (no pass over J); the value is the fresh evaluation's to 1e-9 n, an
+    edited state is evaluated from scratch, and a later replica call does not leave stale rows behind."""
+    n, R = 4100, 4
+    J, b, _ = _system(n, 17, False)
+    rng = np.random.default_rng(2)
+    sts = rng.integers(0, 2, size=(R, n)).astype(np.int8)
+    d = _dense(J, b, False)
+    for call in range(3):
+        out = d.sweep_replicas(sts, [1.0, 1.2, 1.4, 1.6], 1, [5] * R, [call] * R, replicas=list(range(R)))
+        fresh = d.energies(out)
+        for r in (2, 0, 3, 1):
+            d.set_state(out[r])
+            assert abs(d.energy() - fresh[r]) <= 1e-9 * n, (call, r)
+        edited = out[1].copy()
+        edited[11] ^= 1
+        d.set_state(edited)
+        assert abs(d.energy() - d.energies(edited[None])[0]) <= 1e-9 * n
+        sts = out[::-1].copy()  # the next call sees them in another order
+    d.close()
+
+
 def test_replica_batch_of_eleven_and_replayed_uniforms():
     # eleven replicas = a launch of eight and one of three (padded to four); replayed uniforms per replica
     n, R, k = 2560, 11, 2

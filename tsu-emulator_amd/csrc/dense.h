@@ -46,6 +46,7 @@ struct tsu_dense {
     int rep_prev_n;         // how many there are (0: none)
     int rep_cur;
     int rep_since;          // sweeps since the replicas' fields were last computed from scratch
+    int rep_match;          // the resident state (tsu_dense_set_state) IS row rep_match - 1 of rep_prev: tsu_dense_energy takes its kept fields (0: no)
     int co_disabled;    // cooperative launch unavailable or failed once: use the multi-launch path
     unsigned long long* pp_masks;  // k2_pipe: flip-mask granules of the solver teams
     int pp_failed;      // k2_pipe ran and left the state half updated: the caller restores it, later calls skip the pipeline

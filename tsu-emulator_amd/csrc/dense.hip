@@ -901,6 +901,11 @@ int tsu_dense_set_state(tsu_dense* d, const int8_t* bits_host) {
     TSU_HIP_TRY(d->ctx, hipStreamSynchronize(d->ctx->stream));
     d->fields_valid = 0;  // the pipeline's kept fields belong to the old state
     d->pipe_streak = 0;
+    // ... but the state may be one the last replica call returned (a tempering loop asks for every replica's energy between its
+    // sweeps, gibbs.py:303-323): its fields are still there
+    d->rep_match = 0;
+    for (int p = 0; p < d->rep_prev_n && !d->rep_match; ++p)
+        if (memcmp(bits_host, d->rep_prev + (size_t)p * d->n, (size_t)d->n) == 0) d->rep_match = p + 1;
     return TSU_OK;
 }
 
@@ -1009,6 +1014,7 @@ int tsu_dense_sweep(tsu_dense* d, double T, int n_sweeps, const int64_t* order, 
     // converge within its iteration slots
     if (!(use_coop && !d->co_disabled && !order && d->n >= 2 * DB)) {  // another path writes the state: the pipeline's kept fields go stale
         d->fields_valid = 0;
+        d->rep_match = 0;
         d->pipe_streak = 0;
     }
     if (use_coop && !d->co_disabled && !order && d->n >= 2 * DB) {
@@ -1208,6 +1214,7 @@ int tsu_dense_sweep_replicas(tsu_dense* d, int n_replicas, const double* tempera
             TSU_REQUIRE(ctx, states_host[(size_t)r * n + i] == 0 || states_host[(size_t)r * n + i] == 1, "dense_set_state: state must be 0/1");
     }
     if (n_sweeps == 0) return TSU_OK;
+    d->rep_match = 0;  // (the kept rows are about to change)
     const int wave_m = k2w_slots(d);
     const bool wg = !wave_m && k2wg_takes(d);
     if (!wave_m && !wg) {
@@ -1347,6 +1354,8 @@ int tsu_dense_energy(tsu_dense* d, double* energy) {
     const double* fields = d->field;
     if (d->fields_valid && d->co_fields) {
         fields = d->co_fields;
+    } else if (d->rep_match > 0 && d->rep_match <= d->rep_prev_n && d->rep_fields[d->rep_cur]) {
+        fields = d->rep_fields[d->rep_cur] + (size_t)(d->rep_match - 1) * d->n;
     } else {
         unsigned mv_grid = (unsigned)(((size_t)d->n * 64 + 255) / 256);
         if (d->dtype == TSU_DTYPE_F64)

@@ -1094,6 +1094,7 @@ int tsu_dense_pipe_run(tsu_dense* d, double T, const double* temps_dev, int n_to
     bool fields_were_valid = d->fields_valid != 0;
     const int streak = d->pipe_streak;
     d->fields_valid = 0;
+    d->rep_match = 0;
     d->pipe_streak = 0;
     if (n_total <= 0) return TSU_OK;
     if (!d->own_failed) {
@@ -1123,6 +1124,7 @@ int tsu_dense_coop_sweep(tsu_dense* d, double T, int n_sweeps, uint64_t seed, ui
     bool fields_were_valid = d->fields_valid != 0;
     const int streak = d->pipe_streak;
     d->fields_valid = 0;
+    d->rep_match = 0;
     d->pipe_streak = 0;
     *done = 0;
     if (!d->own_failed) {
