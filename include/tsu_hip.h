@@ -253,7 +253,7 @@ int tsu_langevin_get_state(tsu_langevin* l, float* x_host);
 int tsu_langevin_set_energy(tsu_langevin* l, const float* k_host, const float* mu_host); /* dim each */
 /* COUPLED quadratic energy E = 1/2 x^T A x + b^T x: A_host dim*dim row-major and SYMMETRIC (checked), b_host dim or NULL.
  * The gradient A x + b replaces _numerical_gradient (tsu/core.py:82-98) for the reference's multivariate callers
- * (tsu/api.py:94); dim <= 32768.  tsu_langevin_step then makes one launch per step (every new element needs the whole old
+ * (tsu/api.py:94); dim <= 65536.  tsu_langevin_step then makes one launch per step (every new element needs the whole old
  * state); restart / set_state / get_state / trajectories as for the separable energy. */
 int tsu_langevin_set_coupling(tsu_langevin* l, const float* A_host, const float* b_host);
 /* x <- x_init + amp * N(0,1) per chain (core.py:142-143); chain c uses Philox chain id chain0+c */

@@ -21,7 +21,7 @@ def _spd(d, seed, cond=20.0):
     return A32
 
 
-@pytest.mark.parametrize("d,chains", [(5, 1), (64, 3), (100, 8), (257, 20), (1024, 2), (1500, 9)])
+@pytest.mark.parametrize("d,chains", [(5, 1), (64, 3), (100, 8), (257, 20), (1024, 2), (1500, 9), (4000, 9)])  # (4000 x 9: two column chunks)
 def test_coupled_steps_match_the_twin(d, chains):
     from tsu import _hip
     A = _spd(d, d)

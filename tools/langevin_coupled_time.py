@@ -25,7 +25,7 @@ for rep in range(3):
     best = min(best, ctx.timer_end() / steps)
 P = (d + 63) // 64 * 64
 cb = 8
-while cb > 1 and (cb // 2 >= chains or (P * cb + 16 * cb * 64) * 4 > 150 * 1024):
+while cb > 1 and cb // 2 >= chains:
     cb //= 2
 blocks = (chains + cb - 1) // cb
 print(f"d={d} chains={chains}: {best * 1e3:.1f} us per step; A read {blocks} x per step = {blocks * P * P * 4 / (best * 1e-3) / 1e12:.2f} TB/s; "

@@ -86,18 +86,13 @@ __global__ __launch_bounds__(256) void k3_langevin(float* __restrict__ x, const 
 #define K3C_WAVES 16
 template <int CB>
 __global__ __launch_bounds__(K3C_THREADS) void k3_coupled(const float* __restrict__ xin, float* __restrict__ xout, const float* __restrict__ A,
-                                                          const float* __restrict__ bvec, int n_chains, int dim, int pitch, int P, float a,
+                                                          const float* __restrict__ bvec, int n_chains, int dim, int pitch, int P, int JC, float a,
                                                           float scale, uint32_t k0, uint32_t k1, uint32_t step, uint32_t chain0,
                                                           float* __restrict__ traj) {
     extern __shared__ float k3c_lds[];
-    float* xT = k3c_lds;                    // [P][CB] the chains' states, chain fastest
-    float* red = xT + (size_t)P * CB;       // [K3C_WAVES][CB][64]
+    float* xT = k3c_lds;                    // [JC][CB] a chunk of JC columns of the chains' states, chain fastest
+    float* red = xT + (size_t)JC * CB;      // [K3C_WAVES][CB][64]
     const int rb = (int)blockIdx.x, c0 = (int)blockIdx.y * CB;
-    for (int q = (int)threadIdx.x; q < P * CB; q += K3C_THREADS) {
-        const int j = q / CB, c = q - j * CB;
-        xT[q] = (j < dim && c0 + c < n_chains) ? xin[(size_t)(c0 + c) * pitch + j] : 0.0f;
-    }
-    __syncthreads();
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int q16 = lane & 15, t = lane >> 4;
     const int col0 = 64 * rb + 4 * q16;
@@ -107,25 +102,35 @@ __global__ __launch_bounds__(K3C_THREADS) void k3_coupled(const float* __restric
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc[c][m] = 0.0f;
     constexpr int U = 4;  // bundles (4 rows of A each) in flight per lane
-    const int nb = P / 4;  // (a multiple of 16)
-    for (int bnd = wv; bnd < nb; bnd += K3C_WAVES * U) {
-        float4 av[U];
+    // the columns in chunks of JC (the LDS holds JC columns of CB chains: 8 chains whatever the dimension); the accumulators run on
+    for (int j0 = 0; j0 < P; j0 += JC) {
+        const int jc = P - j0 < JC ? P - j0 : JC;  // (a multiple of 64)
+        if (j0) __syncthreads();  // (the previous chunk has been read by every wave)
+        for (int q = (int)threadIdx.x; q < jc * CB; q += K3C_THREADS) {
+            const int j = j0 + q / CB, c = q % CB;
+            xT[q] = (j < dim && c0 + c < n_chains) ? xin[(size_t)(c0 + c) * pitch + j] : 0.0f;
+        }
+        __syncthreads();
+        const int nb = jc / 4;  // (a multiple of 16)
+        for (int bnd = wv; bnd < nb; bnd += K3C_WAVES * U) {
+            float4 av[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (bnd + K3C_WAVES * u < nb) av[u] = *reinterpret_cast<const float4*>(A + (size_t)(4 * (bnd + K3C_WAVES * u) + t) * P + col0);
+            for (int u = 0; u < U; ++u)
+                if (bnd + K3C_WAVES * u < nb) av[u] = *reinterpret_cast<const float4*>(A + (size_t)(j0 + 4 * (bnd + K3C_WAVES * u) + t) * P + col0);
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (bnd + K3C_WAVES * u < nb) {
-                const float* xs = xT + (size_t)(4 * (bnd + K3C_WAVES * u) + t) * CB;
+            for (int u = 0; u < U; ++u)
+                if (bnd + K3C_WAVES * u < nb) {
+                    const float* xs = xT + (size_t)(4 * (bnd + K3C_WAVES * u) + t) * CB;
 #pragma unroll
-                for (int c = 0; c < CB; ++c) {
-                    const float xv = xs[c];
-                    acc[c][0] = __fmaf_rn(av[u].x, xv, acc[c][0]);
-                    acc[c][1] = __fmaf_rn(av[u].y, xv, acc[c][1]);
-                    acc[c][2] = __fmaf_rn(av[u].z, xv, acc[c][2]);
-                    acc[c][3] = __fmaf_rn(av[u].w, xv, acc[c][3]);
+                    for (int c = 0; c < CB; ++c) {
+                        const float xv = xs[c];
+                        acc[c][0] = __fmaf_rn(av[u].x, xv, acc[c][0]);
+                        acc[c][1] = __fmaf_rn(av[u].y, xv, acc[c][1]);
+                        acc[c][2] = __fmaf_rn(av[u].z, xv, acc[c][2]);
+                        acc[c][3] = __fmaf_rn(av[u].w, xv, acc[c][3]);
+                    }
                 }
-            }
+        }
     }
     // the four entry slots of a quad (fixed order), then the sixteen waves through LDS
 #pragma unroll
@@ -156,22 +161,30 @@ __global__ __launch_bounds__(K3C_THREADS) void k3_coupled(const float* __restric
         float n[4];
         box_muller4(wd, n);
         const float nz = (i & 3) == 0 ? n[0] : (i & 3) == 1 ? n[1] : (i & 3) == 2 ? n[2] : n[3];
-        const float v = __fmaf_rn(scale, nz, __fmaf_rn(-g, a, xT[(size_t)i * CB + c]));
+        const float v = __fmaf_rn(scale, nz, __fmaf_rn(-g, a, xin[(size_t)ch * pitch + i]));
         xout[(size_t)ch * pitch + i] = v;
         if (traj) traj[(size_t)ch * pitch + i] = v;
     }
+}
+
+// columns per chunk: as many as the LDS holds for CB chains next to the partial sums (144 KB in all), a multiple of 64, at most P
+static int k3c_chunk(int P, int cb) {
+    const int budget = 144 * 1024 - K3C_WAVES * cb * 64 * 4;
+    int jc = (budget / 4 / cb) / 64 * 64;
+    return jc < P ? jc : P;
 }
 
 template <int CB>
 static hipError_t k3c_launch(tsu_langevin* l, const float* xin, float* xout, float a, float scale, uint64_t seed, uint32_t step, uint32_t chain0,
                              float* traj) {
     tsu_ctx* ctx = l->ctx;
-    const size_t lds = ((size_t)l->P * CB + (size_t)K3C_WAVES * CB * 64) * sizeof(float);
+    const int JC = k3c_chunk(l->P, CB);
+    const size_t lds = ((size_t)JC * CB + (size_t)K3C_WAVES * CB * 64) * sizeof(float);
     hipError_t e = tsu_func_allow_lds(ctx, (const void*)k3_coupled<CB>, (int)lds);
     if (e != hipSuccess) return e;
     const dim3 grid((unsigned)(l->P / 64), (unsigned)((l->n_chains + CB - 1) / CB));
-    hipLaunchKernelGGL(k3_coupled<CB>, grid, dim3(K3C_THREADS), lds, ctx->stream, xin, xout, l->A, l->b, l->n_chains, l->dim, l->pitch, l->P, a, scale,
-                       (uint32_t)seed, (uint32_t)(seed >> 32), step, chain0, traj);
+    hipLaunchKernelGGL(k3_coupled<CB>, grid, dim3(K3C_THREADS), lds, ctx->stream, xin, xout, l->A, l->b, l->n_chains, l->dim, l->pitch, l->P, JC, a,
+                       scale, (uint32_t)seed, (uint32_t)(seed >> 32), step, chain0, traj);
     return hipGetLastError();
 }
 
@@ -279,8 +292,7 @@ int tsu_langevin_set_coupling(tsu_langevin* l, const float* A_host, const float*
     tsu_ctx* ctx = l->ctx;
     TSU_REQUIRE(ctx, A_host != nullptr, "langevin_set_coupling: NULL matrix");
     const int d = l->dim, P = l->P;
-    // chains per workgroup are bounded by the LDS (the states of a block of chains, all P columns): P <= 32768 for one chain
-    TSU_REQUIRE(ctx, (size_t)P * 4 + (size_t)K3C_WAVES * 64 * 4 <= 150 * 1024, "langevin_set_coupling: dim %d is beyond the coupled kernel's range (32768)", d);
+    TSU_REQUIRE(ctx, d <= 65536, "langevin_set_coupling: dim %d is beyond the coupled kernel's range (65536: a 16 GiB matrix)", d);
     for (int i = 0; i < d; ++i)
         for (int j = 0; j < i; ++j)
             TSU_REQUIRE(ctx, A_host[(size_t)i * d + j] == A_host[(size_t)j * d + i], "langevin_set_coupling: the matrix must be symmetric (entry %d, %d)", i, j);
@@ -341,9 +353,9 @@ int tsu_langevin_step(tsu_langevin* l, int n_steps, float dt, float gamma, float
     if (traj_host) TSU_HIP_TRY(ctx, hipMalloc(&d_traj, (size_t)n_steps * l->n_chains * l->pitch * sizeof(float)));
     hipError_t e = hipSuccess;
     if (l->have_energy == 2) {
-        // chains per workgroup: as many as the LDS holds next to the partial sums, at most 8, no more than there are chains
+        // chains per workgroup (one stream of A serves them all): at most 8, no more than there are chains
         int cb = 8;
-        while (cb > 1 && (cb / 2 >= l->n_chains || ((size_t)l->P * cb + (size_t)K3C_WAVES * cb * 64) * sizeof(float) > 150 * 1024)) cb /= 2;
+        while (cb > 1 && cb / 2 >= l->n_chains) cb /= 2;
         for (int s = 0; s < n_steps && e == hipSuccess; ++s) {
             float* tr = d_traj ? d_traj + (size_t)s * l->n_chains * l->pitch : nullptr;
             const uint32_t st = step0 + (uint32_t)s;
