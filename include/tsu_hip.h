@@ -205,11 +205,16 @@ int tsu_dense_anneal(tsu_dense* d, const double* temperatures, int n_steps, cons
 /* The replica loop of GibbsSampler.parallel_tempering (tsu/gibbs.py:300-306): replica r does n_sweeps sweeps of its own
  * state (states_host[r*n .. ], in and out) at temperatures[r] with its own seed / sweep counter / replica id;
  * replay_uniforms: NULL or n_replicas * n_sweeps * n doubles.  The handle's resident state is not used.  n <= 192 (fp32 J; 128 for fp64): one
- * launch, one wave per replica; up to 576 (448) sites one workgroup per replica; larger systems are swept one replica after the other. */
+ * launch, one wave per replica; up to 576 (448) sites one workgroup per replica; from 2048 sites on (a multiple of 4) up to eight
+ * replicas advance together in one launch of the owner-computes kernel on ONE stream of J (groups of eight one after the other).
+ * Up to eight replicas' fields stay on the device: a state that comes back byte for byte as one the previous call returned -- in
+ * any position, as after a tempering swap -- resumes from that state's fields instead of a pass over J. */
 int tsu_dense_sweep_replicas(tsu_dense* d, int n_replicas, const double* temperatures, int n_sweeps, int8_t* states_host,
                              const uint64_t* seeds, const uint32_t* sweep0s, const uint32_t* replicas,
                              const double* replay_uniforms);
-int tsu_dense_energy(tsu_dense* d, double* energy); /* -1/2 s^T J s - b^T s of the resident state */
+/* -1/2 s^T J s - b^T s of the resident state (from the fields the last sweep call kept for it, or -- a state set with
+ * tsu_dense_set_state that the last replica call returned -- from that replica's kept fields; otherwise one pass over J) */
+int tsu_dense_energy(tsu_dense* d, double* energy);
 /* the same for n_states given states (states_host: n_states x n bytes of 0/1; the resident state is not touched): the energies of
  * the states an annealing schedule recorded (simulated_annealing, gibbs.py:384-391, evaluates compute_energy after every step) */
 int tsu_dense_energies(tsu_dense* d, const int8_t* states_host, int n_states, double* energies_host);
