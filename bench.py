@@ -283,6 +283,21 @@ def time_dense(hip, ctx, counters, n=16384):
     out["eight_replicas"] = {"ms_per_all_replica_sweep": ms_8, "vs_single_chain_sweep": ms_8 / ms, "replica_sweeps_per_s": R / (ms_8 * 1e-3),
                              "note": "8 states advanced together by one launch; wall clock incl. the states' PCIe round trip (128 KiB each way)"}
     d.close()
+    # the same system with fp64 couplings (the drop-in's default dtype: the reference's J is float64): 2 GiB streamed per sweep
+    d = hip.DenseSystem(J.astype(np.float64), None, hip.DTYPE_F64, ctx=ctx)
+    d.set_state(np.random.default_rng(42).integers(0, 2, size=n).astype(np.int8))
+    d.sweep(1.0, 2, seed=1, sweep0=0)
+    d.sweep(1.0, 2, seed=1, sweep0=2)
+    ms64 = 1e30
+    for rep in range(2):
+        ctx.synchronize()
+        ctx.timer_begin()
+        d.sweep(1.0, 8, seed=1, sweep0=4 + 8 * rep)
+        ms64 = min(ms64, ctx.timer_end() / 8)
+    d.close()
+    out["f64"] = {"ms_per_sweep": ms64, "J_stream_GBps": n * n * 8 / (ms64 * 1e-3) / 1e9,
+                  "roofline_frac": n * n * 8 / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                  "note": "fp64 couplings: algorithmic N^2 x 8 B per sweep; same kernel (k2_own<double>), the rows of J^T of the sites that change"}
     return out
 
 

@@ -2,6 +2,7 @@
 usage: own_order_time.py [n] [sweeps]"""
 import sys, time
 sys.path.insert(0, "tsu-emulator_amd"); sys.path.insert(0, ".")
+import os
 import numpy as np
 from tsu import _hip as hip
 ctx = hip.Context.default()
@@ -11,7 +12,7 @@ rng = np.random.default_rng(n)
 G = rng.standard_normal((n, n)).astype(np.float32)
 J = ((G + G.T) / 2 / np.sqrt(n)).astype(np.float32)
 np.fill_diagonal(J, 0.0)
-d = hip.DenseSystem(J, None, hip.DTYPE_F32, ctx=ctx)
+d = hip.DenseSystem(J.astype(np.float64) if os.environ.get('TSU_TOOL_F64') else J, None, hip.DTYPE_F64 if os.environ.get('TSU_TOOL_F64') else hip.DTYPE_F32, ctx=ctx)  # (TSU_TOOL_F64=1: the fp64 kernels)
 d.set_state(rng.integers(0, 2, size=n).astype(np.int8))
 order = np.array([rng.permutation(n) for _ in range(k)])
 d.sweep(1.0, 2, seed=1, sweep0=0, order=order[:2])
