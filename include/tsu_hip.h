@@ -216,7 +216,8 @@ int tsu_dense_sweep_replicas(tsu_dense* d, int n_replicas, const double* tempera
  * tsu_dense_set_state that the last replica call returned -- from that replica's kept fields; otherwise one pass over J) */
 int tsu_dense_energy(tsu_dense* d, double* energy);
 /* the same for n_states given states (states_host: n_states x n bytes of 0/1; the resident state is not touched): the energies of
- * the states an annealing schedule recorded (simulated_annealing, gibbs.py:384-391, evaluates compute_energy after every step) */
+ * the states an annealing schedule recorded (simulated_annealing, gibbs.py:384-391, evaluates compute_energy after every step);
+ * states the last replica call returned are evaluated from their kept fields */
 int tsu_dense_energies(tsu_dense* d, const int8_t* states_host, int n_states, double* energies_host);
 /* launches of the one-launch kernels this system has made so far (counts[0]: owner-computes kernel k2_own, counts[1]: pipeline
  * k2_pipe) -- lets a caller or a test see which path its sweeps took (no reference counterpart) */

@@ -183,6 +183,11 @@ def test_energy_of_a_replica_state_comes_from_its_kept_fields():
         edited[11] ^= 1
         d.set_state(edited)
         assert abs(d.energy() - d.energies(edited[None])[0]) <= 1e-9 * n
+        # tsu_dense_energies takes the kept fields too; against a system that never swept replicas (one pass over J per state)
+        if call == 0:
+            d2 = _dense(J, b, False)
+            np.testing.assert_allclose(fresh, d2.energies(out), rtol=0, atol=1e-9 * n)
+            d2.close()
         sts = out[::-1].copy()  # the next call sees them in another order
     d.close()
 

@@ -1401,6 +1401,15 @@ int tsu_dense_energies(tsu_dense* d, const int8_t* states_host, int n_states, do
     const unsigned mv_grid = (unsigned)((n * 64 + 255) / 256);
     for (int k = 0; k < n_states && e == hipSuccess; ++k) {  // one pass over J per state, all on the stream, one wait at the end
         const int8_t* s = d->samples + (size_t)k * n;
+        // ... unless the state is one the last replica call returned: its fields are still on the device (a tempering ladder asks
+        // for its chains' energies between their sweeps)
+        const double* kept = nullptr;
+        for (int p = 0; p < d->rep_prev_n && !kept && d->rep_fields[d->rep_cur]; ++p)
+            if (memcmp(states_host + (size_t)k * n, d->rep_prev + (size_t)p * n, n) == 0) kept = d->rep_fields[d->rep_cur] + (size_t)p * n;
+        if (kept) {
+            k2_energy<<<1, 1024, 0, ctx->stream>>>(kept, s, d->bias, d_e + k, d->n);
+            continue;
+        }
         if (d->dtype == TSU_DTYPE_F64)
             k2_matvec<double><<<mv_grid, 256, 0, ctx->stream>>>((const double*)d->J, s, d->bias, d->field, d->n);
         else
