@@ -562,6 +562,28 @@ def test_langevin_matches_oracle(hip, n_chains, dim):
     np.testing.assert_allclose(lc.get_state(), wantr, rtol=0, atol=LANGEVIN_ATOL)
 
 
+def test_langevin_uniform_energy_is_the_general_kernel_with_scalars(hip):
+    """One stiffness and one centre for every element (`QuadraticEnergy(2.0)`, the README's energies) runs the kernel variant that
+    takes them as scalars -- no loads beside the state's; the same arithmetic: bit for bit what the general variant makes of the same
+    numbers (an array whose LAST element differs selects the general variant; all other elements must agree exactly), and the oracle's
+    trajectory within the fp32 tolerance."""
+    n_chains, dim = 3, 1030
+    x = np.random.default_rng(1).normal(size=(n_chains, dim)).astype(np.float32)
+    a = hip.LangevinChains(n_chains, dim)
+    a.set_energy(1.75, 0.25)
+    a.set_state(x)
+    a.step(15, 0.02, 1.5, 0.7, 99, step0=2, chain0=4)
+    k = np.full(dim, 1.75, np.float32)
+    k[-1] = 1.5
+    b = hip.LangevinChains(n_chains, dim)
+    b.set_energy(k, np.full(dim, 0.25, np.float32))
+    b.set_state(x)
+    b.step(15, 0.02, 1.5, 0.7, 99, step0=2, chain0=4)
+    np.testing.assert_array_equal(a.get_state()[:, :-1], b.get_state()[:, :-1])
+    want = ora.langevin_quadratic_f32(x, 1.75, 0.25, 15, 0.02, 1.5, 0.7, 99, step0=2, chain0=4)
+    np.testing.assert_allclose(a.get_state(), want, rtol=0, atol=LANGEVIN_ATOL)
+
+
 def test_langevin_stationary_variance(hip):
     """dim 2^16 chains-as-elements: var -> T / (k (1 - k dt / (2 gamma))) = 0.505051 for k=2, dt=0.01."""
     lc = hip.LangevinChains(1, 1 << 16)

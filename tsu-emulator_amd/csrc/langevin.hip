@@ -35,6 +35,8 @@ struct tsu_langevin {
     float* xinit;
     int steps_per_launch;
     int have_energy;  // 0: none; 1: separable (k, mu); 2: coupled (A, b)
+    int uniform;      // separable with ONE stiffness and ONE centre for every element: the kernel takes them as scalars
+    float k0v, mu0v;
     float* A;         // [P][P], P = dim rounded up to 64, zero padded
     float* b;         // [P]
     float* x2;        // the other buffer of a coupled step (every element of the new state needs the whole old one)
@@ -55,11 +57,11 @@ static __device__ __forceinline__ void box_muller4(const u32x4& w, float n[4]) {
 }
 
 // one thread = one quad of one chain; n_steps fused in registers; optional trajectory write per step
-template <bool GRID2D>
+template <bool GRID2D, bool UNI>
 __global__ __launch_bounds__(256) void k3_langevin(float* __restrict__ x, const float* __restrict__ k,
                                                   const float* __restrict__ mu, int n_chains, int quads, int pitch,
                                                   int n_steps, float a, float scale, uint32_t k0, uint32_t k1,
-                                                  uint32_t step0, uint32_t chain0, float* __restrict__ traj) {
+                                                  uint32_t step0, uint32_t chain0, float* __restrict__ traj, float ku, float muu) {
     int ch, q;
     if (GRID2D) {  // (blockIdx.y = chain: no 64-bit division per thread)
         ch = (int)blockIdx.y;
@@ -78,8 +80,16 @@ __global__ __launch_bounds__(256) void k3_langevin(float* __restrict__ x, const 
     k3_f4* px = reinterpret_cast<k3_f4*>(x + (long long)ch * pitch) + q;
     const k3_f4 xin = __builtin_nontemporal_load(px);
     float4 xv = make_float4(xin.x, xin.y, xin.z, xin.w);
-    float4 kv = reinterpret_cast<const float4*>(k)[q];
-    float4 mv = reinterpret_cast<const float4*>(mu)[q];
+    // (UNI: one stiffness and one centre for every element -- E = k/2 sum (x - mu)^2, the README's energies: passed in place of the
+    // pointers' first elements, no loads beside the state's)
+    float4 kv, mv;
+    if (UNI) {
+        kv = make_float4(ku, ku, ku, ku);
+        mv = make_float4(muu, muu, muu, muu);
+    } else {
+        kv = reinterpret_cast<const float4*>(k)[q];
+        mv = reinterpret_cast<const float4*>(mu)[q];
+    }
     for (int s = 0; s < n_steps; ++s) {
         u32x4 w = tsu_philox((uint32_t)q, chain0 + (uint32_t)ch, step0 + (uint32_t)s, TSU_TAG_LANGEVIN, k0, k1);
         float n[4];
@@ -240,6 +250,8 @@ int tsu_langevin_create(tsu_ctx* ctx, int n_chains, int dim, tsu_langevin** out)
     l->P = (dim + 63) / 64 * 64;
     l->steps_per_launch = 0;
     l->have_energy = 0;
+    l->uniform = 0;
+    l->k0v = l->mu0v = 0.0f;
     size_t xb = (size_t)n_chains * l->pitch * sizeof(float), vb = (size_t)l->pitch * sizeof(float);
     hipError_t e = hipMalloc(&l->x, xb);
     if (e == hipSuccess) e = hipMalloc(&l->k, vb);
@@ -301,6 +313,11 @@ int tsu_langevin_set_energy(tsu_langevin* l, const float* k_host, const float* m
     TSU_HIP_TRY(l->ctx, hipMemcpyAsync(l->mu, mu_host, w, hipMemcpyHostToDevice, l->ctx->stream));
     TSU_HIP_TRY(l->ctx, hipStreamSynchronize(l->ctx->stream));
     l->have_energy = 1;
+    l->uniform = 1;
+    for (int i = 1; i < l->dim && l->uniform; ++i)
+        if (k_host[i] != k_host[0] || mu_host[i] != mu_host[0]) l->uniform = 0;
+    l->k0v = k_host[0];
+    l->mu0v = mu_host[0];
     return TSU_OK;
 }
 
@@ -388,12 +405,16 @@ int tsu_langevin_step(tsu_langevin* l, int n_steps, float dt, float gamma, float
         for (int s = 0; s < n_steps; s += per) {
             int ns = n_steps - s < per ? n_steps - s : per;
             float* tr = d_traj ? d_traj + (size_t)s * l->n_chains * l->pitch : nullptr;
-            if (l->n_chains <= 65535)
-                k3_langevin<true><<<dim3((unsigned)((quads + 255) / 256), (unsigned)l->n_chains), 256, 0, ctx->stream>>>(
-                    l->x, l->k, l->mu, l->n_chains, quads, l->pitch, ns, a, scale, (uint32_t)seed, (uint32_t)(seed >> 32), step0 + (uint32_t)s, chain0, tr);
-            else
-                k3_langevin<false><<<grid, 256, 0, ctx->stream>>>(l->x, l->k, l->mu, l->n_chains, quads, l->pitch, ns, a, scale, (uint32_t)seed,
-                                                                  (uint32_t)(seed >> 32), step0 + (uint32_t)s, chain0, tr);
+            const dim3 g2((unsigned)((quads + 255) / 256), (unsigned)l->n_chains);
+#define K3_ARGS l->x, l->k, l->mu, l->n_chains, quads, l->pitch, ns, a, scale, (uint32_t)seed, (uint32_t)(seed >> 32), step0 + (uint32_t)s, chain0, tr, l->k0v, l->mu0v
+            if (l->n_chains <= 65535) {
+                if (l->uniform) k3_langevin<true, true><<<g2, 256, 0, ctx->stream>>>(K3_ARGS);
+                else k3_langevin<true, false><<<g2, 256, 0, ctx->stream>>>(K3_ARGS);
+            } else {
+                if (l->uniform) k3_langevin<false, true><<<grid, 256, 0, ctx->stream>>>(K3_ARGS);
+                else k3_langevin<false, false><<<grid, 256, 0, ctx->stream>>>(K3_ARGS);
+            }
+#undef K3_ARGS
         }
     }
     if (e == hipSuccess) e = hipGetLastError();
