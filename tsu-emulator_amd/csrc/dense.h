@@ -46,6 +46,9 @@ struct tsu_dense {
     int rep_prev_n;         // how many there are (0: none)
     int rep_cur;
     int rep_since;          // sweeps since the replicas' fields were last computed from scratch
+    unsigned* h_flags;      // pinned host words: the owner kernel's error flags land here without a staged copy
+    int8_t* h_stage;        // pinned host buffer (n bytes + 8): get_state / energy come back through it (a copy into the caller's
+                            // pageable memory is staged by the runtime and costs ~10 us more)
     int rep_match;          // the resident state (tsu_dense_set_state) IS row rep_match - 1 of rep_prev: tsu_dense_energy takes its kept fields (0: no)
     int co_disabled;    // cooperative launch unavailable or failed once: use the multi-launch path
     unsigned long long* pp_masks;  // k2_pipe: flip-mask granules of the solver teams

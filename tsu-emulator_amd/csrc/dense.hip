@@ -878,6 +878,8 @@ int tsu_dense_destroy(tsu_dense* d) {
     if (d->rep_fields[0]) (void)hipFree(d->rep_fields[0]);
     if (d->rep_fields[1]) (void)hipFree(d->rep_fields[1]);
     free(d->rep_prev);
+    if (d->h_flags) (void)hipHostFree(d->h_flags);
+    if (d->h_stage) (void)hipHostFree(d->h_stage);
     if (d->co_logit) (void)hipFree(d->co_logit);
     if (d->co_corr) (void)hipFree(d->co_corr);
     if (d->co_d0) (void)hipFree(d->co_d0);
@@ -890,6 +892,15 @@ int tsu_dense_destroy(tsu_dense* d) {
     if (d->own_gran) (void)hipFree(d->own_gran);
     delete d;
     return TSU_OK;
+}
+
+// the handle's pinned staging buffer (n bytes for a state, 8 more for an energy), made on first use; nullptr: copy directly
+static int8_t* dense_stage(tsu_dense* d) {
+    if (!d->h_stage && hipHostMalloc((void**)&d->h_stage, (((size_t)d->n + 7) / 8) * 8 + 8, hipHostMallocDefault) != hipSuccess) {
+        d->h_stage = nullptr;
+        (void)hipGetLastError();
+    }
+    return d->h_stage;
 }
 
 int tsu_dense_set_state(tsu_dense* d, const int8_t* bits_host) {
@@ -913,8 +924,10 @@ int tsu_dense_get_state(tsu_dense* d, int8_t* bits_host) {
     TSU_ENTER(d ? d->ctx : nullptr);
     if (!d) return TSU_E_INVALID;
     TSU_REQUIRE(d->ctx, bits_host != nullptr, "dense_get_state: NULL");
-    TSU_HIP_TRY(d->ctx, hipMemcpyAsync(bits_host, d->state, (size_t)d->n, hipMemcpyDeviceToHost, d->ctx->stream));
+    int8_t* stage = dense_stage(d);
+    TSU_HIP_TRY(d->ctx, hipMemcpyAsync(stage ? stage : bits_host, d->state, (size_t)d->n, hipMemcpyDeviceToHost, d->ctx->stream));
     TSU_HIP_TRY(d->ctx, hipStreamSynchronize(d->ctx->stream));
+    if (stage) memcpy(bits_host, stage, (size_t)d->n);
     return TSU_OK;
 }
 
@@ -1365,8 +1378,11 @@ int tsu_dense_energy(tsu_dense* d, double* energy) {
     }
     k2_energy<<<1, 1024, 0, ctx->stream>>>(fields, d->state, d->bias, d->d_energy, d->n);
     TSU_HIP_TRY(ctx, hipGetLastError());
-    TSU_HIP_TRY(ctx, hipMemcpyAsync(energy, d->d_energy, 8, hipMemcpyDeviceToHost, ctx->stream));
+    int8_t* stage = dense_stage(d);
+    void* dst = stage ? (void*)(stage + (((size_t)d->n + 7) / 8) * 8) : (void*)energy;
+    TSU_HIP_TRY(ctx, hipMemcpyAsync(dst, d->d_energy, 8, hipMemcpyDeviceToHost, ctx->stream));
     TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (stage) memcpy(energy, dst, 8);
     return TSU_OK;
 }
 

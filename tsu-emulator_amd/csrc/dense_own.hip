@@ -1472,7 +1472,13 @@ int tsu_dense_own_run(tsu_dense* d, int R_real, const OwnRep* reps, int8_t* stat
         const int rcx = tsu_grid_exclusive_end(ctx);
         if (rcx != TSU_OK) return rcx;
     }
-    unsigned h[4];
+    // (the error words come back into pinned memory: a copy into pageable memory is staged and costs ~10 us more per call)
+    if (!d->h_flags && hipHostMalloc((void**)&d->h_flags, 4 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) {
+        d->h_flags = nullptr;
+        (void)hipGetLastError();
+    }
+    unsigned hbuf[4];
+    unsigned* h = d->h_flags ? d->h_flags : hbuf;
     TSU_HIP_TRY(ctx, hipMemcpyAsync(h + 1, d->co_bar + BAR_ERR, 3 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
     TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (d_tl) {
