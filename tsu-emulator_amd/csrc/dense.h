@@ -47,6 +47,7 @@ struct tsu_dense {
     int rep_cur;
     int rep_since;          // sweeps since the replicas' fields were last computed from scratch
     unsigned* h_flags;      // pinned host words: the owner kernel's error flags land here without a staged copy
+    int8_t* h_rep;          // pinned host buffer of 8 n bytes: a group of replica states travels in ONE copy each way
     int8_t* h_stage;        // pinned host buffer (n bytes + 8): get_state / energy come back through it (a copy into the caller's
                             // pageable memory is staged by the runtime and costs ~10 us more)
     int rep_match;          // the resident state (tsu_dense_set_state) IS row rep_match - 1 of rep_prev: tsu_dense_energy takes its kept fields (0: no)

@@ -880,6 +880,7 @@ int tsu_dense_destroy(tsu_dense* d) {
     free(d->rep_prev);
     if (d->h_flags) (void)hipHostFree(d->h_flags);
     if (d->h_stage) (void)hipHostFree(d->h_stage);
+    if (d->h_rep) (void)hipHostFree(d->h_rep);
     if (d->co_logit) (void)hipFree(d->co_logit);
     if (d->co_corr) (void)hipFree(d->co_corr);
     if (d->co_d0) (void)hipFree(d->co_d0);
@@ -892,6 +893,19 @@ int tsu_dense_destroy(tsu_dense* d) {
     if (d->own_gran) (void)hipFree(d->own_gran);
     delete d;
     return TSU_OK;
+}
+
+// every byte 0 or 1?  (eight at a time: the byte-by-byte check of eight replicas' states took 0.1 ms per call at n = 16384)
+static bool dense_bits01(const int8_t* p, size_t n) {
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        memcpy(&w, p + i, 8);
+        if (w & 0xFEFEFEFEFEFEFEFEull) return false;
+    }
+    for (; i < n; ++i)
+        if (p[i] != 0 && p[i] != 1) return false;
+    return true;
 }
 
 // the handle's pinned staging buffer (n bytes for a state, 8 more for an energy), made on first use; nullptr: copy directly
@@ -907,7 +921,7 @@ int tsu_dense_set_state(tsu_dense* d, const int8_t* bits_host) {
     TSU_ENTER(d ? d->ctx : nullptr);
     if (!d) return TSU_E_INVALID;
     TSU_REQUIRE(d->ctx, bits_host != nullptr, "dense_set_state: NULL");
-    for (int i = 0; i < d->n; ++i) TSU_REQUIRE(d->ctx, bits_host[i] == 0 || bits_host[i] == 1, "dense_set_state: state must be 0/1");
+    TSU_REQUIRE(d->ctx, dense_bits01(bits_host, (size_t)d->n), "dense_set_state: state must be 0/1");
     TSU_HIP_TRY(d->ctx, hipMemcpyAsync(d->state, bits_host, (size_t)d->n, hipMemcpyHostToDevice, d->ctx->stream));
     TSU_HIP_TRY(d->ctx, hipStreamSynchronize(d->ctx->stream));
     d->fields_valid = 0;  // the pipeline's kept fields belong to the old state
@@ -1223,8 +1237,7 @@ int tsu_dense_sweep_replicas(tsu_dense* d, int n_replicas, const double* tempera
     const int n = d->n;
     for (int r = 0; r < n_replicas; ++r) {
         TSU_REQUIRE(ctx, temperatures[r] > 0.0, "Temperature must be positive");
-        for (int i = 0; i < n; ++i)
-            TSU_REQUIRE(ctx, states_host[(size_t)r * n + i] == 0 || states_host[(size_t)r * n + i] == 1, "dense_set_state: state must be 0/1");
+        TSU_REQUIRE(ctx, dense_bits01(states_host + (size_t)r * n, (size_t)n), "dense_set_state: state must be 0/1");
     }
     if (n_sweeps == 0) return TSU_OK;
     d->rep_match = 0;  // (the kept rows are about to change)
@@ -1254,6 +1267,10 @@ int tsu_dense_sweep_replicas(tsu_dense* d, int n_replicas, const double* tempera
             }
             int8_t* ds = (int8_t*)d->rep_buf;
             double* du = ub_ ? (double*)((char*)d->rep_buf + ((sb_ + 7) / 8) * 8) : nullptr;
+            if (!d->h_rep && hipHostMalloc((void**)&d->h_rep, (size_t)8 * n, hipHostMallocDefault) != hipSuccess) {
+                d->h_rep = nullptr;
+                (void)hipGetLastError();
+            }
             // one group of replicas: their fields stay on the device from call to call; a state that comes back byte for byte as one
             // of those the last call returned (in any position: tempering swaps them) resumes from that state's fields
             const bool keep = n_replicas <= 8;
@@ -1288,11 +1305,13 @@ int tsu_dense_sweep_replicas(tsu_dense* d, int n_replicas, const double* tempera
                 reps[q].tag = TSU_TAG_DENSE | (replicas[r] << 8);
                 reps[q].k0 = (uint32_t)seeds[r];
                 reps[q].k1 = (uint32_t)(seeds[r] >> 32);
-                TSU_HIP_TRY(ctx, hipMemcpyAsync(ds + (size_t)q * n, states_host + (size_t)r * n, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+                if (d->h_rep) memcpy(d->h_rep + (size_t)q * n, states_host + (size_t)r * n, (size_t)n);
+                else TSU_HIP_TRY(ctx, hipMemcpyAsync(ds + (size_t)q * n, states_host + (size_t)r * n, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
                 if (du)
                     TSU_HIP_TRY(ctx, hipMemcpyAsync(du + (size_t)q * n_sweeps * n, replay_uniforms + (size_t)r * n_sweeps * n, (size_t)n_sweeps * n * 8,
                                                     hipMemcpyHostToDevice, ctx->stream));
             }
+            if (d->h_rep) TSU_HIP_TRY(ctx, hipMemcpyAsync(ds, d->h_rep, (size_t)mp * n, hipMemcpyHostToDevice, ctx->stream));
             int done = 0;
             const int rc = tsu_dense_own_run(d, mp, reps, ds, n_sweeps, du, nullptr, nullptr, nullptr, 0, 1, all_known, can_keep, &done);
             if (rc != TSU_OK) {
@@ -1305,8 +1324,9 @@ int tsu_dense_sweep_replicas(tsu_dense* d, int n_replicas, const double* tempera
                 all_done = false;
                 break;
             }
-            TSU_HIP_TRY(ctx, hipMemcpyAsync(states_host + (size_t)r0 * n, ds, (size_t)m * n, hipMemcpyDeviceToHost, ctx->stream));
+            TSU_HIP_TRY(ctx, hipMemcpyAsync(d->h_rep ? d->h_rep : states_host + (size_t)r0 * n, ds, (size_t)m * n, hipMemcpyDeviceToHost, ctx->stream));
             TSU_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (d->h_rep) memcpy(states_host + (size_t)r0 * n, d->h_rep, (size_t)m * n);
             if (can_keep) {
                 memcpy(d->rep_prev, states_host + (size_t)r0 * n, (size_t)m * n);
                 d->rep_prev_n = m;
@@ -1400,8 +1420,7 @@ int tsu_dense_energies(tsu_dense* d, const int8_t* states_host, int n_states, do
     TSU_REQUIRE(ctx, n_states >= 0 && (n_states == 0 || (states_host && energies_host)), "dense_energies: NULL / negative count");
     if (n_states == 0) return TSU_OK;
     const size_t n = (size_t)d->n;
-    for (size_t i = 0; i < n * (size_t)n_states; ++i)
-        TSU_REQUIRE(ctx, states_host[i] == 0 || states_host[i] == 1, "dense_energies: states must be 0/1");
+    TSU_REQUIRE(ctx, dense_bits01(states_host, n * (size_t)n_states), "dense_energies: states must be 0/1");
     // the states share the sample buffer (it is only ever a staging area of one call), the energies get a scratch array
     if (d->samples_cap < n * (size_t)n_states) {
         if (d->samples) (void)hipFree(d->samples);
