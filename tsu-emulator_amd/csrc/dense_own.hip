@@ -1446,10 +1446,14 @@ int tsu_dense_own_run(tsu_dense* d, int R_real, const OwnRep* reps, int8_t* stat
     P.rec_from = rec_from;
     P.rec_every = rec_every > 0 ? rec_every : 1;
     P.fail_at = own_env("TSU_K2_OWN_TEST_FAIL", -1);
+    // lists a deciding wave gathers by itself: up to 32 entries in natural order, 48 in a caller's order and for replicas (n = 16384:
+    // natural order is flat from 16 to 32, the other two from 48 to 64); a replica's own short list has 64 slots
     P.solo_max = own_env("TSU_K2_OWN_SOLO_MAX", (ord || R > 1) ? 48 : OWN_SOLO_MAX);
-    if (P.solo_max > 64) P.solo_max = 64;  // (a replica's own short list has 64 slots)
-    if (P.solo_max < 0) P.solo_max = 0;  // (n = 16384: natural order flat from 16 to 32, a caller's order from 48 to 64)
-    P.solo = own_env("TSU_K2_OWN_SOLO", 1) && (ord ? NP <= 256 : NP <= 64) && (R == 1 || M == 1);  // (one polled group per lane; the switch is read per call: A/B measurements)
+    if (P.solo_max > 64) P.solo_max = 64;
+    if (P.solo_max < 0) P.solo_max = 0;
+    // solo generations (one chain): the deciding wave polls one group per lane in natural order, four in a caller's order.  (Replicas
+    // always run their generations wave by wave: rep_step.)  Both switches are read per call: A/B measurements.
+    P.solo = own_env("TSU_K2_OWN_SOLO", 1) && (ord ? NP <= 256 : NP <= 64) && (R == 1 || M == 1);
     for (int r = 0; r < R; ++r) P.rep[r] = reps[r < R_real ? r : 0];  // (padding replicas repeat replica 0 on its own state copy: see the caller)
     static const int keep_fields = own_env("TSU_K2_KEEP_FIELDS", 1);
     const bool single = R_real == 1 && allow_persist;
