@@ -18,8 +18,14 @@
 //   * A caller's visiting order (update_order="random": one permutation per sweep): a superblock is a range of POSITIONS, its sites
 //     are spread over all workgroups, so every workgroup is active in every superblock, follows every generation and applies every
 //     toggle to all its rows (unmasked: the running field) and to the rows that come later in the order (masked: the decision).
-//   * Replicas (tempering ladders, independent chains on ONE J): R states advance together; a row of J^T is loaded once for the
-//     union of the replicas' toggles and applied to each replica's accumulator with that replica's sign.
+//   * Replicas (tempering ladders, independent chains on ONE J): R states advance together, one deciding wave per replica: wave rho
+//     polls replica rho's granules, scans its toggles and gathers short lists by itself (rep_step); long lists go to all sixteen
+//     waves as a union list -- a row of J^T loaded once for the union of the replicas' toggles and applied to each replica's
+//     accumulator with that replica's sign -- built by all sixteen waves (build_par).  The replicas' fields stay on the device
+//     from call to call (dense.h: rep_fields).
+//   * Solo generations (one chain): after the first correction pass a generation moves a handful of sites; the deciding wave then
+//     runs it alone -- decide, publish, poll, scan, gather, reduce -- with no workgroup barrier; the other waves are called in for
+//     long lists only.
 #include <algorithm>
 #include <vector>
 
