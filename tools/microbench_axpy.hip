@@ -423,6 +423,8 @@ int main(int argc, char** argv) {
         }
         std::sort(pick.begin(), pick.end());
         for (int k = 0; k < nl; ++k) h[(size_t)r * nl + k] = (uint32_t)pick[k] | (1u << 16) | ((k & 1) << 17);
+        if (argc > 5 && argv[5][0] == 's' && r > 0)  // "same": every pass reads the SAME rows (cache-hot after the first)
+            for (int k = 0; k < nl; ++k) h[(size_t)r * nl + k] = h[k];
     }
     uint32_t* lists;
     CHECK(hipMalloc(&lists, h.size() * 4));
@@ -454,7 +456,7 @@ int main(int argc, char** argv) {
               {"rep2 4 scalar 4 vector", axpy_rep2<16, 0, 6, 4>}, {"rep2 4 scalar 4 vector arithmetic only", axpy_rep2<16, 2, 6, 4>},
               {"rep2 5 scalar 3 vector", axpy_rep2<16, 0, 6, 5>}, {"rep2 5 scalar 3 vector arithmetic only", axpy_rep2<16, 2, 6, 5>},
               {"rep2 readlane U=8", axpy_rep2<8, 0, 1>}, {"rep2 movrels U=8", axpy_rep2<8, 0, 2>}};
-    if (argc > 5) {  // calibration of the byte counters: ONE launch of the kernel k2_own runs, reading W x nl x reps x 256 bytes
+    if (argc > 5 && argv[5][0] == 'c') {  // calibration of the byte counters: ONE launch of the kernel k2_own runs, reading W x nl x reps x 256 bytes
         axpy_quad<4, false><<<W, 1024>>>(J, n, lists, nl, reps, out);
         CHECK(hipDeviceSynchronize());
         printf("calibration launch: %.0f bytes of row segments\n", (double)W * nl * reps * 256.0);
